@@ -1,0 +1,252 @@
+"""ctypes binding of the CPU oracle (oracle/libnerf_oracle.so).
+
+TEST INFRASTRUCTURE ONLY: importable from tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg.  Nothing under nerf-rs_amd/ may import this module.
+"""
+import ctypes as C
+import json
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libnerf_oracle.so")
+_lib = None
+
+f32p = C.POINTER(C.c_float)
+
+
+class Camera(C.Structure):
+    _fields_ = [("nx", C.c_int32), ("ny", C.c_int32),
+                ("alpha_width", C.c_float), ("alpha_height", C.c_float),
+                ("pos", C.c_float * 3), ("dir", C.c_float * 3), ("up", C.c_float * 3),
+                ("near", C.c_float), ("far", C.c_float)]
+
+
+class Opts(C.Structure):
+    _fields_ = [("n_coarse", C.c_int32), ("n_fine", C.c_int32), ("coarse_only", C.c_int32),
+                ("crop_x0", C.c_int32), ("crop_y0", C.c_int32), ("crop_w", C.c_int32), ("crop_h", C.c_int32),
+                ("ssaa", C.c_int32), ("seed", C.c_uint64), ("naive_order", C.c_int32), ("n_threads", C.c_int32)]
+
+
+class RayDump(C.Structure):
+    _fields_ = [("dir_hat", C.c_float * 3),
+                ("t_coarse", f32p), ("sigma_coarse", f32p), ("w_coarse", f32p), ("cdf", f32p),
+                ("u_fine", f32p), ("t_new", f32p),
+                ("t_merged", f32p), ("sigma_fine", f32p), ("rgb_fine", f32p), ("w_fine", f32p),
+                ("rgb", C.c_float * 3), ("n_new", C.c_int32)]
+
+
+def build(force=False):
+    src = [os.path.join(_HERE, n) for n in ("nerf_oracle.c", "nerf_oracle.h", "Makefile")]
+    if (not force and os.path.exists(_LIB_PATH)
+            and all(os.path.getmtime(_LIB_PATH) >= os.path.getmtime(s) for s in src)):
+        return _LIB_PATH
+    subprocess.check_call(["make", "-s", "-C", _HERE, "-B", "libnerf_oracle.so"])
+    return _LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            build()
+        L = C.CDLL(_LIB_PATH)
+        L.oracle_net_load_dir.restype = C.c_void_p
+        L.oracle_net_load_dir.argtypes = [C.c_char_p, C.c_char_p, C.c_size_t]
+        L.oracle_net_free.argtypes = [C.c_void_p]
+        L.oracle_uniform.restype = C.c_float
+        L.oracle_uniform.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32]
+        L.oracle_philox4x32.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                        C.POINTER(C.c_uint32)]
+        L.oracle_forward_batch.argtypes = [C.c_void_p, f32p, f32p, C.c_size_t, f32p, f32p, C.c_int]
+        L.oracle_positional_encoding.argtypes = [f32p, C.c_size_t, C.c_int, f32p]
+        L.oracle_camera_from_values.argtypes = [C.c_float, C.c_float, f32p, f32p, f32p, f32p, C.c_int, C.c_int,
+                                                C.POINTER(Camera)]
+        L.oracle_get_ray_dir.argtypes = [C.POINTER(Camera), C.c_int, C.c_int, f32p]
+        L.oracle_get_ray_dir_nohalf.argtypes = [C.POINTER(Camera), C.c_int, C.c_int, f32p]
+        L.oracle_normalize.argtypes = [f32p, f32p]
+        L.oracle_stratified_samples.argtypes = [C.c_uint64, C.c_uint32, C.c_float, C.c_float, C.c_int, f32p]
+        L.oracle_compute_weights.argtypes = [f32p, f32p, C.c_int, C.c_float, f32p]
+        L.oracle_sample_importance_u.restype = C.c_int
+        L.oracle_sample_importance_u.argtypes = [f32p, f32p, f32p, C.c_int, C.c_int, f32p, f32p]
+        L.oracle_sample_importance.restype = C.c_int
+        L.oracle_sample_importance.argtypes = [C.c_uint64, C.c_uint32, f32p, f32p, C.c_int, C.c_int, f32p]
+        L.oracle_sort_ascending.argtypes = [f32p, C.c_int]
+        L.oracle_integrate_ray.argtypes = [f32p, f32p, f32p, C.c_int, C.c_float, f32p]
+        L.oracle_render_image.restype = C.c_int
+        L.oracle_render_image.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(Camera), C.POINTER(Opts), f32p]
+        L.oracle_render_ray_debug.restype = C.c_int
+        L.oracle_render_ray_debug.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(Camera), C.POINTER(Opts),
+                                              C.c_int, C.c_int, C.POINTER(RayDump)]
+        L.oracle_quantize_rgb8.argtypes = [f32p, C.c_size_t, C.POINTER(C.c_uint8)]
+        L.oracle_save_ppm.restype = C.c_int
+        L.oracle_save_ppm.argtypes = [C.c_char_p, C.c_int, C.c_int, f32p]
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(f32p)
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+class Net:
+    def __init__(self, directory):
+        err = C.create_string_buffer(512)
+        self.h = lib().oracle_net_load_dir(str(directory).encode(), err, 512)
+        if not self.h:
+            raise RuntimeError(err.value.decode())
+
+    def forward_batch(self, pts_soa, dirs_aos, naive=False):
+        """pts_soa: (3, n) f32; dirs_aos: (n, 3) f32 -> (rgb (n,3), sigma (n,))."""
+        pts = _f32(pts_soa)
+        dirs = _f32(dirs_aos)
+        n = pts.shape[1]
+        assert pts.shape == (3, n) and dirs.shape == (n, 3)
+        rgb = np.empty((n, 3), np.float32)
+        sig = np.empty((n,), np.float32)
+        lib().oracle_forward_batch(self.h, _p(pts), _p(dirs), n, _p(rgb), _p(sig), int(naive))
+        return rgb, sig
+
+    def __del__(self):
+        try:
+            if self.h:
+                lib().oracle_net_free(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+
+def load_samples(path):
+    with open(path) as f:
+        return json.load(f)
+
+
+def camera_from_samples(samples, width, height):
+    cam = Camera()
+    o = _f32(samples["camera_origin"]); fw = _f32(samples["camera_forward"]); up = _f32(samples["camera_up"])
+    hwf = _f32(samples["hwf"])
+    lib().oracle_camera_from_values(np.float32(samples["near"]), np.float32(samples["far"]), _p(o), _p(fw), _p(up),
+                                    _p(hwf), width, height, C.byref(cam))
+    return cam
+
+
+def make_opts(n_coarse=64, n_fine=128, coarse_only=False, crop=None, ssaa=1, seed=0, naive=False, threads=0):
+    o = Opts()
+    o.n_coarse, o.n_fine, o.coarse_only = n_coarse, n_fine, int(coarse_only)
+    if crop:
+        o.crop_x0, o.crop_y0, o.crop_w, o.crop_h = crop
+    o.ssaa, o.seed, o.naive_order, o.n_threads = ssaa, seed, int(naive), threads
+    return o
+
+
+def uniform(seed, pixel, stream, k):
+    return float(lib().oracle_uniform(seed, pixel, stream, k))
+
+
+def philox(seed, c0, c1, c2, c3):
+    out = (C.c_uint32 * 4)()
+    lib().oracle_philox4x32(seed, c0, c1, c2, c3, out)
+    return [int(x) for x in out]
+
+
+def get_ray_dir(cam, i, j, half=True):
+    out = np.empty(3, np.float32)
+    (lib().oracle_get_ray_dir if half else lib().oracle_get_ray_dir_nohalf)(C.byref(cam), i, j, _p(out))
+    return out
+
+
+def normalize(v):
+    v = _f32(v); out = np.empty(3, np.float32)
+    lib().oracle_normalize(_p(v), _p(out))
+    return out
+
+
+def stratified_samples(seed, pixel, near, far, count):
+    t = np.empty(count, np.float32)
+    lib().oracle_stratified_samples(seed, pixel, near, far, count, _p(t))
+    return t
+
+
+def compute_weights(sigmas, t, far):
+    s = _f32(sigmas); t = _f32(t); w = np.empty_like(t)
+    lib().oracle_compute_weights(_p(s), _p(t), len(t), far, _p(w))
+    return w
+
+
+def sample_importance_u(u, samples, weights):
+    u = _f32(u); s = _f32(samples); w = _f32(weights)
+    out = np.empty(len(u), np.float32)
+    cdf = np.empty(max(len(s) - 1, 1), np.float32)
+    n = lib().oracle_sample_importance_u(_p(u), _p(s), _p(w), len(s), len(u), _p(out), _p(cdf))
+    return out[:n], cdf
+
+
+def sample_importance(seed, pixel, samples, weights, count):
+    s = _f32(samples); w = _f32(weights)
+    out = np.empty(count, np.float32)
+    n = lib().oracle_sample_importance(seed, pixel, _p(s), _p(w), len(s), count, _p(out))
+    return out[:n]
+
+
+def sort_ascending(v):
+    v = _f32(v).copy()
+    lib().oracle_sort_ascending(_p(v), len(v))
+    return v
+
+
+def integrate_ray(colors, sigmas, t, far):
+    c = _f32(colors); s = _f32(sigmas); t = _f32(t)
+    out = np.empty(3, np.float32)
+    lib().oracle_integrate_ray(_p(c), _p(s), _p(t), len(t), far, _p(out))
+    return out
+
+
+def render_image(coarse, fine, cam, opts):
+    w = opts.crop_w if opts.crop_w > 0 else cam.nx
+    h = opts.crop_h if opts.crop_h > 0 else cam.ny
+    out = np.empty((h, w, 3), np.float32)
+    rc = lib().oracle_render_image(coarse.h, fine.h, C.byref(cam), C.byref(opts), _p(out))
+    if rc:
+        raise RuntimeError(f"oracle_render_image failed: {rc}")
+    return out
+
+
+def render_ray_debug(coarse, fine, cam, opts, i, j):
+    nc, nf = opts.n_coarse, (0 if opts.coarse_only else opts.n_fine)
+    nm = nc + nf
+    arrs = dict(t_coarse=np.zeros(nc, np.float32), sigma_coarse=np.zeros(nc, np.float32),
+                w_coarse=np.zeros(nc, np.float32), cdf=np.zeros(max(nc - 1, 1), np.float32),
+                u_fine=np.zeros(max(nf, 1), np.float32), t_new=np.zeros(max(nf, 1), np.float32),
+                t_merged=np.zeros(nm, np.float32), sigma_fine=np.zeros(nm, np.float32),
+                rgb_fine=np.zeros((nm, 3), np.float32), w_fine=np.zeros(nm, np.float32))
+    d = RayDump()
+    for k, a in arrs.items():
+        setattr(d, k, _p(a))
+    rc = lib().oracle_render_ray_debug(coarse.h, fine.h, C.byref(cam), C.byref(opts), i, j, C.byref(d))
+    if rc:
+        raise RuntimeError(f"oracle_render_ray_debug failed: {rc}")
+    out = dict(arrs)
+    out["dir_hat"] = np.array(list(d.dir_hat), np.float32)
+    out["rgb"] = np.array(list(d.rgb), np.float32)
+    out["n_new"] = int(d.n_new)
+    out["t_new"] = arrs["t_new"][:d.n_new]
+    out["u_fine"] = arrs["u_fine"][:nf]
+    return out
+
+
+def quantize_rgb8(rgb):
+    a = _f32(rgb).reshape(-1, 3)
+    out = np.empty(a.shape, np.uint8)
+    lib().oracle_quantize_rgb8(_p(a), a.shape[0], out.ctypes.data_as(C.POINTER(C.c_uint8)))
+    return out.reshape(np.shape(rgb))
+
+
+def save_ppm(path, rgb):
+    a = _f32(rgb)
+    return lib().oracle_save_ppm(str(path).encode(), a.shape[1], a.shape[0], _p(a))
