@@ -1,0 +1,144 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json's metric on MI355X: rays/s on lego 800x800, 64 coarse + 128 fine samples per ray, fp32.
+
+A "step" is one full frame through the hot path (ray gen -> stratified -> coarse MLP -> resample -> fine MLP ->
+composite [-> RCCL all-gather of the row bands when N > 1]) with weights and all intermediates resident in HBM.
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+Rank 0 prints ONE JSON line.  `roofline` is the fine-network MLP kernel (the dominant launch) measured with HIP
+events on the render stream inside the timed region; `cpu_baseline` is the CPU oracle (a port of the reference's
+algorithm, reference loop order) timed on this host's cores on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_FP32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+
+
+def cpu_baseline(width, height, n_coarse, n_fine, seed):
+    """Oracle (kind: "port") on the host cores: one 8x8 block per thread, forward_fallback's loop order."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle_py as O
+    scene = os.path.join(ROOT, "lego_rust")
+    S = O.load_samples(os.path.join(scene, "tf_reference_samples.json"))
+    co, fi = O.Net(os.path.join(scene, "coarse")), O.Net(os.path.join(scene, "fine"))
+    cam = O.camera_from_samples(S, width, height)
+    cores = len(os.sched_getaffinity(0))
+    # one 8x8 block (the reference's rayon task, src/lib.rs:491,533) per thread, centred on the model
+    bw = 1
+    while bw * bw < cores:
+        bw += 1
+    bh = (cores + bw - 1) // bw
+    crop = (width // 2 - 4 * bw, height // 2 - 4 * bh, 8 * bw, 8 * bh)
+    n_rays = crop[2] * crop[3]
+    t0 = time.time()
+    O.render_image(co, fi, cam, O.make_opts(n_coarse, n_fine, crop=crop, seed=seed, naive=True, threads=cores))
+    dt = time.time() - t0
+    t0 = time.time()
+    O.render_image(co, fi, cam, O.make_opts(n_coarse, n_fine, crop=crop, seed=seed, naive=False, threads=cores))
+    dt_blocked = time.time() - t0
+    return {"value": n_rays / dt, "unit": "rays/s", "cores": cores, "kind": "port",
+            "sample": f"{crop[2]}x{crop[3]} crop at ({crop[0]},{crop[1]}) of the {width}x{height} frame = {n_rays} rays "
+                      f"({n_rays // 64} 8x8 blocks, one per thread), {n_coarse}+{n_fine} samples, reference loop order "
+                      f"(src/network.rs:134-143), {dt:.1f} s; baseline, not target",
+            "cache_blocked_variant_rays_per_s": n_rays / dt_blocked}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--width", type=int, default=800)
+    ap.add_argument("--height", type=int, default=800)
+    ap.add_argument("--coarse", type=int, default=64)
+    ap.add_argument("--fine", type=int, default=128)
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import nerf_rs_amd as N
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU with torch.distributed.run")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm
+
+    scene = os.path.join(ROOT, "lego_rust")
+    r = N.Renderer(local_rank)
+    r.load_scene(scene)
+    cam = N.camera_from_samples(os.path.join(scene, "tf_reference_samples.json"), args.width, args.height, args.coarse)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    frame = torch.empty((args.height, args.width, 3), dtype=torch.float32, device=dev)
+
+    def step():
+        if world == 1:
+            N.render_image(r.coarse, r.fine, cam, args.fine, seed=args.seed, device_out=frame.data_ptr(), stream=stream)
+            return frame
+        return N.render_image_distributed(r.coarse, r.fine, cam, args.fine, seed=args.seed, return_tensor=True)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    r.kernel_time_query(reset=True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    fence()
+    dt = time.perf_counter() - t0
+    ms_dom, pts_dom, n_dom = r.kernel_time_query(reset=True)
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+
+    if rank == 0:
+        n_rays = args.width * args.height
+        flop_ray = N.flop_per_ray(args.coarse, args.fine)
+        value = n_rays * args.steps / dt
+        ach = pts_dom * N.FLOP_PER_POINT_FULL / (ms_dom * 1e-3) / 1e12 if ms_dom > 0 else 0.0
+        line = {
+            "metric": "rays/sec, lego 800x800 (64 coarse + 128 fine samples per ray)", "value": value, "unit": "rays/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+            "data": "real lego weights (lego_rust/, 2 x 595,844 f32 parameters) + tf_reference_samples.json camera; "
+                    "sample positions from the seeded counter RNG (no dataset involved)",
+            "config": {"workload": f"C3: lego coarse+fine hierarchical, {args.width}x{args.height}, {args.coarse}+{args.fine} "
+                                   f"samples/ray, fp32, {world}xMI355X" + (", row bands + RCCL all-gather" if world > 1 else ""),
+                       "rays_per_step": n_rays, "flop_per_ray": flop_ray, "seed": args.seed,
+                       "whole_job_fraction_of_fp32_mfma_roofline": value * flop_ray / (world * PEAK_FP32_MFMA_TFLOPS * 1e12)},
+            "roofline": {"bound": "mfma", "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": ach / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                         "kernel": "nerf_mlp_kernel<FULL=true, MODE_RAYS> (fine network)",
+                         "launches": n_dom, "avg_launch_ms": ms_dom / max(n_dom, 1),
+                         "points_per_launch": pts_dom // max(n_dom, 1), "flop_per_point": N.FLOP_PER_POINT_FULL},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args.width, args.height, args.coarse, args.fine, args.seed)
+        print(json.dumps(line), flush=True)
+    del out
+    r.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

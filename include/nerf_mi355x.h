@@ -1,0 +1,154 @@
+/*
+ * nerf_mi355x.h -- C ABI of libnerf_mi355x.so: the MI355X (gfx950) drop-in for the hot path of
+ * elisabeth96/nerf-rs (ray-march + MLP forward + volume integration).
+ *
+ * The reference has no FFI on this path (it is a single Rust crate); the seams this ABI replaces are
+ *   S2  Network::forward_batch(&self, points: &Matrix [3 x B, SoA], view_dirs: &[Vec3]) -> (Vec<Vec3>, Vec<f32>)
+ *                                                                   reference src/network.rs:197-237
+ *   S3  render_image(&Network, &Network, &Camera, fine_samples_per_ray) -> Vec<Vec3>
+ *                                                                   reference src/lib.rs:474-565
+ * plus the host-side pieces a caller needs around them (loader src/lib.rs:108-174, camera_from_samples
+ * src/lib.rs:614-645, save_ppm src/lib.rs:567-580).  INTEGRATION.md shows the Rust `extern "C"` block a
+ * maintainer of the reference would add to call these from src/lib.rs.
+ *
+ * Conventions: every function returns 0 on success or a negative nerf_status; nerf_last_error() gives the
+ * message (the reference panics instead: src/lib.rs:36,118,127,483-501).  The caller owns all in/out buffers;
+ * the context owns device memory.  Plain pointers and sizes only -- no C++ / torch types.  A context is bound to
+ * one HIP device and is single-caller (one frame at a time); create one context per GPU / per thread.
+ * Everything is f32.  Without the HIP runtime or a gfx950 device nerf_create fails (there is no CPU fallback).
+ */
+#ifndef NERF_MI355X_H
+#define NERF_MI355X_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct nerf_ctx nerf_ctx;
+
+typedef enum {
+    NERF_OK = 0,
+    NERF_ERR_INVALID = -1,   /* bad argument (reference: assert!/panic) */
+    NERF_ERR_IO = -2,        /* "read shapes"/"read tensor" (src/lib.rs:36,65) */
+    NERF_ERR_MISSING = -3,   /* "missing matrix parameter"/"missing bias parameter" (src/lib.rs:118,127) */
+    NERF_ERR_SHAPE = -4,     /* dims mismatch (debug_assert in src/lib.rs:119-120,128-129) */
+    NERF_ERR_HIP = -5,       /* HIP runtime / device error */
+    NERF_ERR_STATE = -6,     /* network not loaded */
+    NERF_ERR_PARSE = -7      /* camera JSON malformed (src/lib.rs:620-631 unwrap/expect) */
+} nerf_status;
+
+enum { NERF_NET_COARSE = 0, NERF_NET_FINE = 1 };
+
+/* Mirrors `struct Camera` (src/lib.rs:197-211); samples_per_ray lives in nerf_render_opts.n_coarse.
+ * alpha_* are the half field-of-view angles (radians); dir/up need not be orthogonal (basis is rebuilt
+ * per src/lib.rs:216-218). */
+typedef struct {
+    int32_t nx, ny;
+    float alpha_width, alpha_height;
+    float pos[3], dir[3], up[3];
+    float near_, far_;
+} nerf_camera;
+
+/* render_image's remaining inputs (src/lib.rs:474-482, 603-612) + the extensions BASELINE.json's configs need.
+ * Zero-initialise, then set n_coarse (> 0).  The reference behaviour is n_coarse=64, n_fine=128, everything else 0. */
+typedef struct {
+    int32_t n_coarse;     /* camera.samples_per_ray */
+    int32_t n_fine;       /* fine_samples_per_ray; 0 => fine net evaluated on the coarse samples only (src/lib.rs:295) */
+    int32_t coarse_only;  /* ext: composite the coarse net's own rgb/sigma, skip the fine pass */
+    int32_t crop_x0, crop_y0, crop_w, crop_h; /* ext: output window in pixels; crop_w = crop_h = 0 => full frame */
+    int32_t ssaa;         /* ext: s x s rays per pixel, box filter; 0 or 1 => off */
+    uint64_t seed;        /* counter-RNG seed (reference: unseeded thread_rng, src/lib.rs:375,407) */
+    int32_t reserved[4];  /* must be 0 */
+} nerf_render_opts;
+
+/* Device-side timing of the last render (HIP events on the render stream). */
+typedef struct {
+    uint64_t n_rays, n_coarse_points, n_fine_points;
+    double ms_total;       /* first kernel -> last kernel */
+    double ms_coarse_mlp;  /* sum over passes */
+    double ms_fine_mlp;
+    double ms_other;       /* ray gen + sampling + compositing + downsample */
+    uint32_t n_mlp_launches;
+    uint32_t n_passes;
+} nerf_stats;
+
+/* ---- lifecycle ------------------------------------------------------------------------------------------ */
+int nerf_create(int device_id, nerf_ctx **out);
+void nerf_destroy(nerf_ctx *ctx);
+/* Message of the last failing call on ctx (or of the last failing context-free call when ctx == NULL). */
+const char *nerf_last_error(const nerf_ctx *ctx);
+int nerf_device_info(const nerf_ctx *ctx, int *n_cus, char *arch_name, size_t arch_name_len);
+
+/* ---- loader: load_network_from_dir (src/lib.rs:108-174), same directory format (shapes.txt + <name>.bin,
+ * little-endian f32, kernels [in][out] row-major), same required tensor names, same failure cases ---------- */
+int nerf_load_network_dir(nerf_ctx *ctx, int which, const char *dir);
+/* For hosts that read the tensors themselves (Rust load_tensor): n named tensors, dims[2*i], dims[2*i+1]
+ * (second = 0 for biases). */
+int nerf_load_network_tensors(nerf_ctx *ctx, int which, int n, const char *const *names, const int64_t *dims,
+                              const float *const *data);
+
+/* Host-only validation of a weight directory (same checks as nerf_load_network_dir, no device needed). */
+int nerf_check_network_dir(const char *dir);
+/* Diagnostic: the packed device images of a weight directory (layout: nerf-rs_amd/csrc/mlp_layout.h).  Pass NULL
+ * buffers to query the lengths (in floats).  Host-only. */
+int nerf_debug_pack_network_dir(const char *dir, float *wstream, size_t wstream_cap, float *small, size_t small_cap,
+                                size_t *wstream_len, size_t *small_len);
+
+/* ---- S2: Network::forward_batch (src/network.rs:197-237) -------------------------------------------------- */
+/* host pointers, synchronous.  n == 0 is a no-op (src/network.rs:199-201). */
+int nerf_forward_batch(nerf_ctx *ctx, int which, const float *pts_soa /*3 x n*/, const float *dirs_aos /*n x 3*/,
+                       size_t n, float *rgb_aos /*n x 3*/, float *sigma /*n*/);
+/* device pointers, asynchronous on `stream` (a hipStream_t passed as void*; NULL = default stream) */
+int nerf_forward_batch_device(nerf_ctx *ctx, int which, const float *d_pts_soa, const float *d_dirs_aos, size_t n,
+                              float *d_rgb_aos, float *d_sigma, void *stream);
+
+/* ---- S3: render_image (src/lib.rs:474-565) ----------------------------------------------------------------- */
+/* rgb_out: crop_h x crop_w x 3 (or ny x nx x 3) linear RGB f32, row-major, index (i*w + j)*3 as image[i*nx+j]
+ * (src/lib.rs:552-557).  Unlike the reference (src/lib.rs:491-501) nx, ny need not be multiples of 8. */
+int nerf_render_image(nerf_ctx *ctx, const nerf_camera *cam, const nerf_render_opts *opts, float *rgb_out,
+                      nerf_stats *stats /* may be NULL */);
+/* device output, asynchronous on `stream`; stats != NULL synchronises the stream before returning. */
+int nerf_render_image_device(nerf_ctx *ctx, const nerf_camera *cam, const nerf_render_opts *opts, float *d_rgb_out,
+                             void *stream, nerf_stats *stats);
+/* Accumulated device time of the dominant (fine- or coarse-only-MLP) kernel since the last reset: blocks until the
+ * recorded events have completed.  Used by bench.py for the roofline line. */
+int nerf_kernel_time_query(nerf_ctx *ctx, double *ms_dominant_mlp, uint64_t *points_dominant_mlp, uint32_t *n_launches,
+                           int reset);
+
+/* ---- host helpers around the path ------------------------------------------------------------------------ */
+/* camera_from_samples (src/lib.rs:614-645): reads near, far, camera_origin, camera_forward, camera_up, hwf. */
+int nerf_camera_from_json(const char *json_path, int width, int height, nerf_camera *out);
+int nerf_camera_from_values(float near_, float far_, const float origin[3], const float forward[3],
+                            const float up[3], const float hwf[3], int width, int height, nerf_camera *out);
+/* save_ppm (src/lib.rs:567-580): P6, (clamp(v,0,1)*255+0.5) as u8 */
+int nerf_save_ppm(const char *path, int width, int height, const float *rgb);
+void nerf_quantize_rgb8(const float *rgb, size_t n_pixels, uint8_t *out);
+
+/* ---- stage entry points (device execution, host buffers): the individual functions of render_block, exposed so
+ * that a host that owns ray setup can call them and so that each stage has its own parity test ------------- */
+/* Camera::get_ray_dir (src/lib.rs:213-231) for the rectangle [y0,y0+h) x [x0,x0+w); normalize != 0 applies
+ * Vec3::normalize (src/lib.rs:371).  out: h x w x 3 */
+int nerf_stage_ray_dirs(nerf_ctx *ctx, const nerf_camera *cam, int x0, int y0, int w, int h, int normalize,
+                        float *dirs_out);
+/* stratified_samples (src/lib.rs:233-248) for the same rectangle; out: h x w x count */
+int nerf_stage_stratified(nerf_ctx *ctx, const nerf_camera *cam, int x0, int y0, int w, int h, int count,
+                          uint64_t seed, float *t_out);
+/* compute_weights + sample_importance + merge/sort (src/lib.rs:250-351, 414-420) for n_rays rays.
+ * u (n_rays x nf) may be NULL => Philox stream 1 of pixel_index[ray].  Outputs may be NULL except t_fine. */
+int nerf_stage_resample(nerf_ctx *ctx, size_t n_rays, int nc, int nf, float far_, uint64_t seed,
+                        const uint32_t *pixel_index, const float *t_coarse, const float *sigma_coarse, const float *u,
+                        float *w_out, float *cdf_out, float *t_new_out, float *t_fine_out);
+/* integrate_ray (src/lib.rs:176-195); w_out (n_rays x n) optional */
+int nerf_stage_integrate(nerf_ctx *ctx, size_t n_rays, int n, float far_, const float *rgb_aos, const float *sigma,
+                         const float *t, float *rgb_out, float *w_out);
+
+/* ABI version: bumped on any signature change. */
+int nerf_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

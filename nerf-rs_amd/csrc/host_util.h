@@ -1,0 +1,46 @@
+// host_util.h -- host-side pieces around the hot path: tensor-directory loader, weight packer, camera,
+// minimal JSON reader, PPM writer.  Internal to libnerf_mi355x.so.
+#pragma once
+#include <stdint.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/nerf_mi355x.h"
+
+namespace nerfhost {
+
+struct Tensor {
+    std::vector<int64_t> dims;
+    std::vector<float> data;
+};
+
+// The 12 layers of one network, by the reference's tensor names (src/lib.rs:133-169).
+struct HostNet {
+    struct L {
+        int K = 0, N = 0;
+        std::vector<float> w, b;
+    };
+    L dense[8], bottleneck, viewdirs, rgb, alpha;
+};
+
+// load_shapes + load_tensor (src/lib.rs:34-42, 62-74).  Returns NERF_OK or an error code + message.
+int read_tensor_dir(const std::string &dir, std::map<std::string, Tensor> &out, std::string &err);
+// take_matrix/take_bias by name (src/lib.rs:115-169) + architecture check for the fused kernel.
+int assemble_net(std::map<std::string, Tensor> &params, HostNet &net, std::string &err);
+
+// Packed device images (mlp_layout.h).
+void pack_network(const HostNet &net, std::vector<float> &wstream, std::vector<float> &small);
+
+// camera_from_samples (src/lib.rs:614-645)
+void camera_from_values(float near_, float far_, const float origin[3], const float forward[3], const float up[3],
+                        const float hwf[3], int width, int height, nerf_camera *out);
+int camera_from_json(const std::string &path, int width, int height, nerf_camera *out, std::string &err);
+// Orthonormal basis + slopes of Camera::get_ray_dir (src/lib.rs:216-218, 225-226)
+void camera_basis(const nerf_camera &cam, float r[3], float u[3], float f[3], float *sx, float *sy);
+
+void quantize_rgb8(const float *rgb, size_t n_pixels, uint8_t *out);
+int save_ppm(const std::string &path, int width, int height, const float *rgb, std::string &err);
+
+} // namespace nerfhost

@@ -1,0 +1,28 @@
+// mlp_kernel.h -- launch interface of the fused MLP kernel (internal to libnerf_mi355x.so).
+#pragma once
+#include <hip/hip_runtime.h>
+
+enum { MLP_MODE_POINTS = 0, MLP_MODE_RAYS = 1 };
+
+struct MlpArgs {
+    const float *wstream;      // packed weight stream (mlp_layout.h), device
+    const float *small_params; // biases + head weights, kSmallFloats floats, device
+    int n_points;
+    int mode;
+    // MLP_MODE_POINTS: forward_batch layouts (src/network.rs:197): points 3 x n SoA, dirs n x 3 AoS
+    const float *pts_soa;
+    const float *dirs_aos;
+    // MLP_MODE_RAYS: point i = sample (i % samples_per_ray) of ray (i / samples_per_ray)
+    const float *ray_dirs; // n_rays x 3, unit
+    const float *t;        // n_rays x samples_per_ray
+    int samples_per_ray;
+    float origin[3];
+    // outputs
+    float *sigma_out; // n
+    float *rgb_out;   // n x 3 (full kernels only)
+};
+
+// Sets the dynamic-LDS attribute of every kernel instantiation on the current device.
+hipError_t nerf_mlp_init();
+// full=false evaluates dense0..7 + alpha only (sigma); n_blocks = persistent workgroups (<= #CUs).
+hipError_t nerf_mlp_launch(const MlpArgs &a, bool full, int n_blocks, hipStream_t stream);

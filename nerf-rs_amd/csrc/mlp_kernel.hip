@@ -1,0 +1,368 @@
+// mlp_kernel.hip -- fused NeRF MLP forward for gfx950 (MI355X), fp32 MFMA.
+//
+// Replaces Network::forward_batch (reference src/network.rs:197-237) and, in ray mode, the point fill of
+// render_block (src/lib.rs:392-402, 432-443): p = origin + d_hat * t.
+//
+// Structure (see mlp_layout.h for the data layout):
+//   * one persistent 256-thread workgroup per CU, 4 waves, each wave owns 32 points per tile;
+//   * a wave's activations (256 features x 32 points) live in 128 registers in the C/D layout of
+//     v_mfma_f32_32x32x2_f32; that layout IS the B-operand layout of the next layer's MFMA once the
+//     weight rows are permuted (done once on the host), so activations never touch LDS or HBM;
+//   * ReLU is applied on the consumer side (one v_max per k-step, hidden under 8 MFMAs);
+//   * biases initialise the accumulators (as the reference does: fill_with_bias, src/network.rs:149-159);
+//   * the packed weight stream (2.3 MB, L2-resident) is DMA'd global->LDS (global_load_lds_dwordx4)
+//     in 16-KiB chunks into a 3-slot ring shared by the 4 waves; one s_barrier per chunk, placed in the
+//     middle of the chunk so the next chunk's first operands can be fetched before they are needed;
+//   * alpha (N=1) and rgb (N=3) heads run on the VALU from the register-resident activations.
+// Per 32-point wave tile: 9280 MFMAs (full) / 7680 (sigma only) x 64 cycles.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "mlp_kernel.h"
+#include "mlp_layout.h"
+
+using namespace nerfmlp;
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define LDS_AS __attribute__((address_space(3)))
+
+namespace {
+
+// ---- weight-stream pipeline -------------------------------------------------------------------
+// The stream is consumed in "macro-steps" of 2 KiB = the A operands of 8 MFMAs (one k-step of an
+// 8-tile layer, or two k-steps of the 4-tile viewdirs layer); 8 macro-steps per 16-KiB chunk.
+struct Pipe {
+    const LDS_AS char *rd;   // LDS address (incl. lane*16) of the NEXT macro-step to fetch
+    const LDS_AS char *ring_lo, *ring_hi; // ring bounds (incl. lane*16)
+    f32x4 a0, a1;            // prefetched A operands of the current macro-step
+    uint32_t ring_addr;      // LDS byte address of the ring + wave*4 KiB (DMA destination base)
+    uint32_t wr_slot_off;    // byte offset of the slot the next DMA chunk goes to
+    uint32_t next_off;       // byte offset in the stream of the next chunk to DMA
+    uint32_t stream_bytes;   // bytes per tile
+    const char *gbase;       // wave-uniform: stream + wave*4 KiB
+    uint32_t lane16;
+};
+
+// Four 1-KiB LDS-DMA pieces (this wave's quarter of a chunk).  Hidden from the compiler's waitcnt
+// bookkeeping on purpose (it would drain vmcnt(0) in front of every later ds_read); completion is
+// enforced by the explicit vmcnt(0) + s_barrier in pipe_sync_prefetch().
+__device__ __forceinline__ void glds_chunk_quarter(uint32_t lane16, const char *gsrc, uint32_t d0) {
+    // No instruction offsets: the immediate of global_load_lds is applied to the global AND the LDS address, so
+    // every piece gets its own scalar base and its own M0 instead.
+    uint32_t keep;
+    const char *g1 = gsrc + 1024, *g2 = gsrc + 2048, *g3 = gsrc + 3072;
+    const uint32_t d1 = d0 + 1024, d2 = d0 + 2048, d3 = d0 + 3072;
+    asm volatile("s_mov_b32 %0, m0\n\t"
+                 "s_mov_b32 m0, %6\n\t"
+                 "s_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, %2\n\t"
+                 "s_mov_b32 m0, %7\n\t"
+                 "s_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, %3\n\t"
+                 "s_mov_b32 m0, %8\n\t"
+                 "s_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, %4\n\t"
+                 "s_mov_b32 m0, %9\n\t"
+                 "s_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, %5\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(lane16), "s"(gsrc), "s"(g1), "s"(g2), "s"(g3), "s"(d0), "s"(d1), "s"(d2), "s"(d3)
+                 : "memory");
+}
+
+__device__ __forceinline__ void pipe_issue(Pipe &P) {
+    uint32_t off = P.next_off, slot = P.wr_slot_off;
+    asm volatile("" : "+s"(off), "+s"(slot)); // keep the running offsets opaque (no 145-way constant folding)
+    glds_chunk_quarter(P.lane16, P.gbase + off, P.ring_addr + slot);
+    off += kChunkBytes;
+    P.next_off = (off == P.stream_bytes) ? 0u : off;
+    slot += kChunkBytes;
+    P.wr_slot_off = (slot == kRingSlots * kChunkBytes) ? 0u : slot;
+}
+
+// Middle of chunk c: chunk c+1 (issued one chunk ago) must have landed; every wave is past chunk c-1, so
+// its slot can be refilled with chunk c+2.
+__device__ __forceinline__ void pipe_sync_prefetch(Pipe &P) {
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    pipe_issue(P);
+}
+
+// Take the prefetched operands of the current macro-step and start fetching the next one.
+__device__ __forceinline__ void pipe_advance(Pipe &P, f32x4 &a0, f32x4 &a1) {
+    a0 = P.a0;
+    a1 = P.a1;
+    P.a0 = *(const LDS_AS f32x4 *)(P.rd);
+    P.a1 = *(const LDS_AS f32x4 *)(P.rd + 1024);
+    const LDS_AS char *n = P.rd + 2048;
+    P.rd = (n == P.ring_hi) ? P.ring_lo : n;
+    // keep the two ds_reads of the NEXT macro-step ahead of this macro-step's MFMAs (otherwise hipcc sinks
+    // them below the MFMAs into the same registers and exposes the LDS latency every 8 MFMAs)
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+__device__ __forceinline__ float relu(float v) {
+    float r;
+    asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(v));
+    return r;
+}
+
+#define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+
+// ---- one input tile (16 k-steps) of a layer with NT output tiles --------------------------------
+// Every input tile starts on a chunk boundary (16 macro-steps for NT=8, 8 for NT=4), so the mid-chunk
+// sync lands on macro-step 4 of every chunk.
+template <int NT, bool RELU>
+__device__ __forceinline__ void tile_steps(const f32x16 &in, f32x16 (&out)[NT], Pipe &P) {
+    static_assert(NT == 8 || NT == 4, "NT");
+    if constexpr (NT == 8) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            f32x4 a0, a1;
+            if ((r & 7) == 4) pipe_sync_prefetch(P);
+            pipe_advance(P, a0, a1);
+            const float b = RELU ? relu(in[r]) : in[r];
+            out[0] = MFMA(a0[0], b, out[0]); out[1] = MFMA(a0[1], b, out[1]);
+            out[2] = MFMA(a0[2], b, out[2]); out[3] = MFMA(a0[3], b, out[3]);
+            out[4] = MFMA(a1[0], b, out[4]); out[5] = MFMA(a1[1], b, out[5]);
+            out[6] = MFMA(a1[2], b, out[6]); out[7] = MFMA(a1[3], b, out[7]);
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+            f32x4 a0, a1;
+            if (r / 2 == 4) pipe_sync_prefetch(P);
+            pipe_advance(P, a0, a1);
+            const float b0 = RELU ? relu(in[r]) : in[r];
+            const float b1 = RELU ? relu(in[r + 1]) : in[r + 1];
+            out[0] = MFMA(a0[0], b0, out[0]); out[1] = MFMA(a0[1], b0, out[1]);
+            out[2] = MFMA(a0[2], b0, out[2]); out[3] = MFMA(a0[3], b0, out[3]);
+            out[0] = MFMA(a1[0], b1, out[0]); out[1] = MFMA(a1[1], b1, out[1]);
+            out[2] = MFMA(a1[2], b1, out[2]); out[3] = MFMA(a1[3], b1, out[3]);
+        }
+    }
+}
+
+template <int NT>
+__device__ __forceinline__ void load_bias(f32x16 (&out)[NT], const LDS_AS float *bias, int h) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const LDS_AS f32x4 *b = (const LDS_AS f32x4 *)(bias + (nt * 2 + h) * 16);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 v = b[q];
+            out[nt][4 * q + 0] = v[0]; out[nt][4 * q + 1] = v[1]; out[nt][4 * q + 2] = v[2]; out[nt][4 * q + 3] = v[3];
+        }
+    }
+}
+
+// hidden 256 -> 256 layer: bias init + 8 input tiles
+template <bool RELU>
+__device__ __forceinline__ void hidden_layer(const f32x16 (&in)[8], f32x16 (&out)[8], const LDS_AS float *bias,
+                                             Pipe &P, int h) {
+    load_bias<8>(out, bias, h);
+#pragma unroll
+    for (int t = 0; t < 8; ++t) tile_steps<8, RELU>(in[t], out, P);
+}
+
+__device__ __forceinline__ float xhalf_sum(float v) { return v + __shfl_xor(v, 32, 64); }
+
+} // namespace
+
+template <bool FULL, int MODE>
+__global__ __launch_bounds__(256, 1) void nerf_mlp_kernel(const MlpArgs A) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const LDS_AS char *lds = (const LDS_AS char *)smem;
+    const LDS_AS float *small = (const LDS_AS float *)(lds + kRingSlots * kChunkBytes);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int p = lane & 31;
+    const int h = lane >> 5;
+    const int lane16 = lane * 16;
+
+    // resident small parameters -> LDS
+    {
+        float *dst = (float *)(smem + kRingSlots * kChunkBytes);
+        for (int i = tid; i < kSmallFloats; i += 256) dst[i] = A.small_params[i];
+    }
+
+    Pipe P;
+    P.lane16 = lane16;
+    P.ring_lo = lds + lane16;
+    P.ring_hi = lds + kRingSlots * kChunkBytes + lane16;
+    P.ring_addr = (uint32_t)(uintptr_t)lds + wave * 4096;
+    P.wr_slot_off = 0;
+    P.next_off = 0;
+    P.stream_bytes = (FULL ? kChunksFull : kChunksSigma) * kChunkBytes;
+    P.gbase = (const char *)A.wstream + wave * 4096;
+    __syncthreads();
+    pipe_issue(P);
+    pipe_issue(P);
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    P.rd = P.ring_lo;
+    {
+        f32x4 d0, d1;
+        pipe_advance(P, d0, d1); // prime: operands of macro-step 0
+    }
+
+    const int n_tiles = (A.n_points + kPointsPerBlock - 1) / kPointsPerBlock;
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int i = tile * kPointsPerBlock + wave * kPointsPerWave + p;
+        const bool valid = i < A.n_points;
+        const int ii = valid ? i : (A.n_points - 1);
+
+        // ---- inputs (src/lib.rs:396 / :436: p = origin + dir_hat * t, mul and add rounded separately)
+        float px, py, pz, dx, dy, dz;
+        if (MODE == MLP_MODE_POINTS) {
+            px = A.pts_soa[ii]; py = A.pts_soa[(size_t)A.n_points + ii]; pz = A.pts_soa[2 * (size_t)A.n_points + ii];
+            dx = A.dirs_aos[3 * (size_t)ii]; dy = A.dirs_aos[3 * (size_t)ii + 1]; dz = A.dirs_aos[3 * (size_t)ii + 2];
+        } else {
+            const int ray = ii / A.samples_per_ray;
+            const float t = A.t[ii];
+            dx = A.ray_dirs[3 * (size_t)ray]; dy = A.ray_dirs[3 * (size_t)ray + 1]; dz = A.ray_dirs[3 * (size_t)ray + 2];
+            px = __fadd_rn(A.origin[0], __fmul_rn(dx, t));
+            py = __fadd_rn(A.origin[1], __fmul_rn(dy, t));
+            pz = __fadd_rn(A.origin[2], __fmul_rn(dz, t));
+        }
+
+        // ---- positional encoding of the point: this lane-half's 32 slots (src/network.rs:263-292)
+        f32x16 E[2];
+        {
+            const float f0 = h ? 32.0f : 1.0f; // octaves 5h .. 5h+4
+            float f = f0;
+#pragma unroll
+            for (int o = 0; o < 5; ++o) {
+                float s, c;
+                sincosf(f * px, &s, &c); E[(6 * o + 0) >> 4][(6 * o + 0) & 15] = s; E[(6 * o + 3) >> 4][(6 * o + 3) & 15] = c;
+                sincosf(f * py, &s, &c); E[(6 * o + 1) >> 4][(6 * o + 1) & 15] = s; E[(6 * o + 4) >> 4][(6 * o + 4) & 15] = c;
+                sincosf(f * pz, &s, &c); E[(6 * o + 2) >> 4][(6 * o + 2) & 15] = s; E[(6 * o + 5) >> 4][(6 * o + 5) & 15] = c;
+                f *= 2.0f;
+            }
+            E[1][14] = h ? pz : px;
+            E[1][15] = h ? 0.0f : py;
+        }
+
+        f32x16 X[8], Y[8];
+
+        // dense0: 64 slots -> 256, output X
+        load_bias<8>(X, small + kBiasOff + 0 * 256, h);
+        tile_steps<8, false>(E[0], X, P);
+        tile_steps<8, false>(E[1], X, P);
+        // dense1..4
+        hidden_layer<true>(X, Y, small + kBiasOff + 1 * 256, P, h);
+        hidden_layer<true>(Y, X, small + kBiasOff + 2 * 256, P, h);
+        hidden_layer<true>(X, Y, small + kBiasOff + 3 * 256, P, h);
+        hidden_layer<true>(Y, X, small + kBiasOff + 4 * 256, P, h);
+        // dense5: [encoding ; h4] -> 256 (skip connection, src/network.rs:209-210)
+        load_bias<8>(Y, small + kBiasOff + 5 * 256, h);
+        tile_steps<8, false>(E[0], Y, P);
+        tile_steps<8, false>(E[1], Y, P);
+#pragma unroll
+        for (int t = 0; t < 8; ++t) tile_steps<8, true>(X[t], Y, P);
+        // dense6, dense7
+        hidden_layer<true>(Y, X, small + kBiasOff + 6 * 256, P, h);
+        hidden_layer<true>(X, Y, small + kBiasOff + 7 * 256, P, h);
+
+        // alpha head on the VALU: sigma = relu(b + sum_F w[F] relu(h8[F]))  (src/network.rs:216)
+        float sigma;
+        {
+            const LDS_AS f32x4 *w = (const LDS_AS f32x4 *)(small + kAlphaWOff + h * 128);
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 wv = w[t * 4 + q];
+                    a0 = fmaf(wv[0], fmaxf(Y[t][4 * q + 0], 0.f), a0);
+                    a1 = fmaf(wv[1], fmaxf(Y[t][4 * q + 1], 0.f), a1);
+                    a2 = fmaf(wv[2], fmaxf(Y[t][4 * q + 2], 0.f), a2);
+                    a3 = fmaf(wv[3], fmaxf(Y[t][4 * q + 3], 0.f), a3);
+                }
+            }
+            sigma = fmaxf(xhalf_sum((a0 + a1) + (a2 + a3)) + small[kMiscOff + 0], 0.f);
+        }
+        if (valid && h == 0) A.sigma_out[i] = sigma;
+
+        if (FULL) {
+            // bottleneck (no activation, src/network.rs:218): Y -> X
+            hidden_layer<true>(Y, X, small + kBiasOff + 8 * 256, P, h);
+            // direction encoding: 16 slots per lane-half (src/network.rs:294-330)
+            f32x16 D;
+            {
+                float f = h ? 4.0f : 1.0f; // octaves 2h, 2h+1
+#pragma unroll
+                for (int o = 0; o < 2; ++o) {
+                    float s, c;
+                    sincosf(f * dx, &s, &c); D[6 * o + 0] = s; D[6 * o + 3] = c;
+                    sincosf(f * dy, &s, &c); D[6 * o + 1] = s; D[6 * o + 4] = c;
+                    sincosf(f * dz, &s, &c); D[6 * o + 2] = s; D[6 * o + 5] = c;
+                    f *= 2.0f;
+                }
+                D[12] = h ? 0.f : dx; D[13] = h ? 0.f : dy; D[14] = h ? 0.f : dz; D[15] = 0.f;
+            }
+            // viewdirs: [bottleneck ; dir encoding] -> 128 (src/network.rs:219-222)
+            f32x16 V[4];
+            load_bias<4>(V, small + kBiasViewOff, h);
+#pragma unroll
+            for (int t = 0; t < 8; ++t) tile_steps<4, false>(X[t], V, P);
+            tile_steps<4, false>(D, V, P);
+            // rgb head on the VALU + sigmoid (src/network.rs:223, :165)
+            float c[3];
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) {
+                const LDS_AS f32x4 *w = (const LDS_AS f32x4 *)(small + kRgbWOff + (h * 3 + ch) * 64);
+                float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const f32x4 wv = w[t * 4 + q];
+                        a0 = fmaf(wv[0], fmaxf(V[t][4 * q + 0], 0.f), a0);
+                        a1 = fmaf(wv[1], fmaxf(V[t][4 * q + 1], 0.f), a1);
+                        a2 = fmaf(wv[2], fmaxf(V[t][4 * q + 2], 0.f), a2);
+                        a3 = fmaf(wv[3], fmaxf(V[t][4 * q + 3], 0.f), a3);
+                    }
+                }
+                const float v = xhalf_sum((a0 + a1) + (a2 + a3)) + small[kMiscOff + 1 + ch];
+                c[ch] = 1.0f / (1.0f + expf(-v));
+            }
+            if (valid && h == 0) {
+                A.rgb_out[3 * (size_t)i + 0] = c[0];
+                A.rgb_out[3 * (size_t)i + 1] = c[1];
+                A.rgb_out[3 * (size_t)i + 2] = c[2];
+            }
+        }
+    }
+    // drain the (unused) prefetches before the LDS allocation is released
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+template <bool FULL, int MODE>
+static hipError_t launch_t(const MlpArgs &a, int n_blocks, hipStream_t stream) {
+    hipLaunchKernelGGL((nerf_mlp_kernel<FULL, MODE>), dim3(n_blocks), dim3(256), kLdsBytes, stream, a);
+    return hipGetLastError();
+}
+
+hipError_t nerf_mlp_init() {
+    const void *ks[4] = {(const void *)nerf_mlp_kernel<true, MLP_MODE_POINTS>, (const void *)nerf_mlp_kernel<false, MLP_MODE_POINTS>,
+                         (const void *)nerf_mlp_kernel<true, MLP_MODE_RAYS>, (const void *)nerf_mlp_kernel<false, MLP_MODE_RAYS>};
+    for (int i = 0; i < 4; ++i) {
+        hipError_t e = hipFuncSetAttribute(ks[i], hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
+hipError_t nerf_mlp_launch(const MlpArgs &a, bool full, int n_blocks, hipStream_t stream) {
+    if (a.n_points <= 0) return hipSuccess;
+    const int n_tiles = (a.n_points + kPointsPerBlock - 1) / kPointsPerBlock;
+    if (n_blocks > n_tiles) n_blocks = n_tiles;
+    if (n_blocks < 1) n_blocks = 1;
+    if (a.mode == MLP_MODE_POINTS)
+        return full ? launch_t<true, MLP_MODE_POINTS>(a, n_blocks, stream) : launch_t<false, MLP_MODE_POINTS>(a, n_blocks, stream);
+    return full ? launch_t<true, MLP_MODE_RAYS>(a, n_blocks, stream) : launch_t<false, MLP_MODE_RAYS>(a, n_blocks, stream);
+}

@@ -1,0 +1,65 @@
+// mlp_layout.h -- shared (host packer + device kernel) description of the packed weight stream.
+//
+// The fused MLP kernel (mlp_kernel.hip) keeps a wave's activations in registers in the C/D layout
+// of v_mfma_f32_32x32x2_f32: a wave owns 32 points; lane l = (p = l & 31, h = l >> 5); an activation
+// "tile" is 16 registers, register r of tile t on lane (p,h) holds feature
+//       F(t, r, h) = 32 t + (r & 3) + 8 (r >> 2) + 4 h            of point p.
+// One MFMA k-step (K = 2) takes register r of input tile t as its B operand (B[k = h][j = p]), so
+// the two k-rows of step s = 16 t + r are features F(t,r,0) and F(t,r,1).  The A operand of the MFMA
+// for output tile nt is therefore  A[i = l & 31][k = l >> 5] = W[row(s, h)][32 nt + i].
+//
+// Weight stream: for each layer, for each k-step s, for each group g of 4 output tiles, one 1-KiB
+// "piece":   piece[(l * 4 + q)] = W[row(s, l >> 5)][32 (4 g + q) + (l & 31)]      (l = lane 0..63)
+// so a wave fetches its A operands for 4 MFMAs with one conflict-free ds_read_b128.  The stream is
+// cut in 16-KiB chunks (= 64/NT k-steps) which the kernel DMA's into a 3-slot LDS ring in order.
+#pragma once
+#include <stdint.h>
+
+namespace nerfmlp {
+
+constexpr int kChunkBytes = 16384;
+constexpr int kChunkFloats = kChunkBytes / 4;
+constexpr int kRingSlots = 3;
+constexpr int kPointsPerWave = 32;
+constexpr int kWavesPerBlock = 4;
+constexpr int kPointsPerBlock = kPointsPerWave * kWavesPerBlock;
+
+// k-steps per layer (K padded to the 32-slot tiles) and output tiles
+constexpr int kStepsL0 = 32;    // 64 encoding slots (63 used)
+constexpr int kStepsHid = 128;  // 256
+constexpr int kStepsL5 = 160;   // 64 encoding slots + 256
+constexpr int kStepsView = 144; // 256 + 32 dir slots (27 used)
+
+constexpr int chunksOf(int steps, int nt) { return steps * nt * 256 / kChunkBytes; }
+
+// layer order in the stream: dense0..dense7, [sigma-only kernels stop here], bottleneck, viewdirs
+constexpr int kChunksSigma = chunksOf(kStepsL0, 8) + 4 * chunksOf(kStepsHid, 8) + chunksOf(kStepsL5, 8) +
+                             2 * chunksOf(kStepsHid, 8);                                  // 120
+constexpr int kChunksFull = kChunksSigma + chunksOf(kStepsHid, 8) + chunksOf(kStepsView, 4); // 145
+
+// small parameters kept resident in LDS (floats)
+constexpr int kBiasOff = 0;                     // 9 layers x [8 nt][2 h][16]  (dense0..7, bottleneck)
+constexpr int kBiasViewOff = kBiasOff + 9 * 256; // [4 nt][2 h][16]
+constexpr int kAlphaWOff = kBiasViewOff + 128;  // [2 h][128]
+constexpr int kRgbWOff = kAlphaWOff + 256;      // [2 h][3 c][64]
+constexpr int kMiscOff = kRgbWOff + 384;        // alpha bias, rgb bias r,g,b
+constexpr int kSmallFloats = ((kMiscOff + 4 + 63) / 64) * 64; // 3136
+constexpr int kSmallBytes = kSmallFloats * 4;
+
+constexpr int kLdsBytes = kRingSlots * kChunkBytes + kSmallBytes;
+
+// feature held by register r (0..15) of a tile on lane-half h, relative to the tile's first feature
+constexpr int regFeature(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+// Encoding slots.  Points: 2 tiles; lane-half h computes octaves 5h..5h+4 (idx 0..29 = 6*o + {sin xyz, cos xyz}),
+// idx 30/31 = raw x,y (h=0) or raw z, zero pad (h=1).  Returns the reference feature row
+// (src/network.rs:263-292: [x,y,z] then per octave sin xyz, cos xyz) or -1 for the pad.
+constexpr int posSlotFeature(int idx, int h) {
+    return idx < 30 ? 3 + 6 * (5 * h + idx / 6) + idx % 6 : (h == 0 ? idx - 30 : (idx == 30 ? 2 : -1));
+}
+// Directions: 1 tile; half h computes octaves 2h..2h+1 (idx 0..11); h=0 idx 12..14 = raw x,y,z; rest pad.
+constexpr int dirSlotFeature(int idx, int h) {
+    return idx < 12 ? 3 + 6 * (2 * h + idx / 6) + idx % 6 : ((h == 0 && idx < 15) ? idx - 12 : -1);
+}
+
+} // namespace nerfmlp

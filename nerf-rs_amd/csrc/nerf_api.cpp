@@ -1,0 +1,645 @@
+// nerf_api.cpp -- context, device memory, render scheduler and the extern "C" boundary (include/nerf_mi355x.h).
+//
+// Host counterpart of render_image / render_block (reference src/lib.rs:353-565): where the reference cuts the
+// frame in 8x8 blocks for rayon workers, this scheduler cuts it in "passes" of whole ray rows (<= max_rays_per_pass
+// rays, all resident in HBM) and runs per pass
+//     ray dirs -> stratified t -> coarse MLP (sigma) -> resample/sort -> fine MLP -> composite
+// as six launches on one stream with no host round trip.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "../../include/nerf_mi355x.h"
+#include "host_util.h"
+#include "mlp_kernel.h"
+#include "mlp_layout.h"
+#include "sampling_kernels.h"
+
+using namespace nerfhost;
+
+namespace {
+
+thread_local std::string g_err; // context-free calls
+
+struct DevNet {
+    float *wstream = nullptr, *small = nullptr;
+    bool loaded = false;
+};
+
+struct EvPair {
+    hipEvent_t a, b;
+    int kind; // 0 coarse mlp, 1 fine mlp (dominant), 2 other
+    uint64_t points;
+};
+
+} // namespace
+
+struct nerf_ctx {
+    int device = 0;
+    int n_cus = 0;
+    std::string arch;
+    std::string err;
+    hipStream_t stream = nullptr; // used by the host-pointer entry points
+    DevNet net[2];
+    // pass workspace
+    size_t ws_rays = 0, ws_nc = 0, ws_m = 0;
+    float *d_dirs = nullptr, *d_tc = nullptr, *d_sc = nullptr, *d_rgbc = nullptr, *d_tf = nullptr, *d_sf = nullptr,
+          *d_rgbf = nullptr;
+    float *d_rayfb = nullptr; size_t rayfb_floats = 0; // SSAA ray framebuffer
+    float *d_out = nullptr; size_t out_floats = 0;       // host-pointer render output staging
+    // scratch for forward_batch / stage calls
+    void *d_scratch = nullptr; size_t scratch_bytes = 0;
+    size_t max_rays_per_pass = (size_t)1 << 20;
+    std::vector<hipEvent_t> ev_pool;
+    std::vector<EvPair> last_render; // events of the last render
+    std::vector<EvPair> dominant;    // accumulated dominant-kernel events (nerf_kernel_time_query)
+};
+
+namespace {
+
+int fail(nerf_ctx *c, int code, const std::string &msg) {
+    if (c) c->err = msg;
+    g_err = msg;
+    return code;
+}
+
+#define HIP_TRY(c, expr)                                                                                    \
+    do {                                                                                                    \
+        hipError_t _e = (expr);                                                                             \
+        if (_e != hipSuccess)                                                                               \
+            return fail((c), NERF_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));              \
+    } while (0)
+
+struct DeviceGuard { // a context is bound to one device; entry points may be called with another one current
+    int prev = -1;
+    bool ok;
+    explicit DeviceGuard(int dev) {
+        ok = hipGetDevice(&prev) == hipSuccess;
+        if (ok && prev != dev) ok = hipSetDevice(dev) == hipSuccess; else if (ok) prev = -1;
+    }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
+hipEvent_t get_event(nerf_ctx *c) {
+    if (!c->ev_pool.empty()) { hipEvent_t e = c->ev_pool.back(); c->ev_pool.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+}
+
+// Event pairs of kind 1 (dominant MLP kernel) are owned by ctx->dominant once a render has finished; every other
+// pair is owned by ctx->last_render.
+void recycle_render(nerf_ctx *c) {
+    for (auto &p : c->last_render) if (p.kind != 1) { c->ev_pool.push_back(p.a); c->ev_pool.push_back(p.b); }
+    c->last_render.clear();
+}
+
+void recycle_dominant(nerf_ctx *c, size_t keep) {
+    while (c->dominant.size() > keep) {
+        c->ev_pool.push_back(c->dominant.front().a); c->ev_pool.push_back(c->dominant.front().b);
+        c->dominant.erase(c->dominant.begin());
+    }
+}
+
+int ensure_bytes(nerf_ctx *c, void **p, size_t *cur, size_t need) {
+    if (*cur >= need) return NERF_OK;
+    if (*p) { HIP_TRY(c, hipDeviceSynchronize()); HIP_TRY(c, hipFree(*p)); *p = nullptr; *cur = 0; }
+    HIP_TRY(c, hipMalloc(p, need));
+    *cur = need;
+    return NERF_OK;
+}
+
+int ensure_workspace(nerf_ctx *c, size_t rays, size_t nc, size_t m) {
+    if (rays <= c->ws_rays && nc <= c->ws_nc && m <= c->ws_m) return NERF_OK;
+    rays = std::max(rays, c->ws_rays); nc = std::max(nc, c->ws_nc); m = std::max(m, c->ws_m);
+    HIP_TRY(c, hipDeviceSynchronize());
+    float **ptrs[] = {&c->d_dirs, &c->d_tc, &c->d_sc, &c->d_rgbc, &c->d_tf, &c->d_sf, &c->d_rgbf};
+    for (auto p : ptrs) if (*p) { HIP_TRY(c, hipFree(*p)); *p = nullptr; }
+    c->ws_rays = c->ws_nc = c->ws_m = 0;
+    HIP_TRY(c, hipMalloc((void **)&c->d_dirs, rays * 3 * sizeof(float)));
+    HIP_TRY(c, hipMalloc((void **)&c->d_tc, rays * nc * sizeof(float)));
+    HIP_TRY(c, hipMalloc((void **)&c->d_sc, rays * nc * sizeof(float)));
+    HIP_TRY(c, hipMalloc((void **)&c->d_rgbc, rays * nc * 3 * sizeof(float)));
+    HIP_TRY(c, hipMalloc((void **)&c->d_tf, rays * m * sizeof(float)));
+    HIP_TRY(c, hipMalloc((void **)&c->d_sf, rays * m * sizeof(float)));
+    HIP_TRY(c, hipMalloc((void **)&c->d_rgbf, rays * m * 3 * sizeof(float)));
+    c->ws_rays = rays; c->ws_nc = nc; c->ws_m = m;
+    return NERF_OK;
+}
+
+int upload_net(nerf_ctx *c, int which, const HostNet &hn) {
+    std::vector<float> ws, sm;
+    pack_network(hn, ws, sm);
+    if (ws.size() != (size_t)nerfmlp::kChunksFull * nerfmlp::kChunkFloats)
+        return fail(c, NERF_ERR_INVALID, "internal: packed stream size mismatch");
+    DevNet &d = c->net[which];
+    if (!d.wstream) HIP_TRY(c, hipMalloc((void **)&d.wstream, ws.size() * sizeof(float)));
+    if (!d.small) HIP_TRY(c, hipMalloc((void **)&d.small, sm.size() * sizeof(float)));
+    HIP_TRY(c, hipMemcpy(d.wstream, ws.data(), ws.size() * sizeof(float), hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(d.small, sm.data(), sm.size() * sizeof(float), hipMemcpyHostToDevice));
+    d.loaded = true;
+    return NERF_OK;
+}
+
+RayGenArgs make_raygen(const nerf_camera &cam, int s) {
+    RayGenArgs g{};
+    g.rnx = cam.nx * s; g.rny = cam.ny * s;
+    g.half = 0.5f; g.normalize = 1;
+    camera_basis(cam, g.r, g.u, g.f, &g.sx, &g.sy);
+    return g;
+}
+
+int check_camera(nerf_ctx *c, const nerf_camera *cam) {
+    if (!cam) return fail(c, NERF_ERR_INVALID, "camera is NULL");
+    if (cam->nx <= 0 || cam->ny <= 0) return fail(c, NERF_ERR_INVALID, "width and height must be greater than zero"); // src/lib.rs:705-709
+    return NERF_OK;
+}
+
+// Record kernel(s) between two events of the given kind.
+struct Timed {
+    nerf_ctx *c; hipStream_t st; EvPair p; bool on;
+    Timed(nerf_ctx *c_, hipStream_t st_, int kind, uint64_t points, bool enable) : c(c_), st(st_), on(enable) {
+        p.kind = kind; p.points = points; p.a = p.b = nullptr;
+        if (on) { p.a = get_event(c); p.b = get_event(c); if (!p.a || !p.b) on = false; else (void)hipEventRecord(p.a, st); }
+    }
+    void done(std::vector<EvPair> &dst) { if (on) { (void)hipEventRecord(p.b, st); dst.push_back(p); } }
+};
+
+int render_device(nerf_ctx *c, const nerf_camera *cam, const nerf_render_opts *o, float *d_out, hipStream_t st,
+                  nerf_stats *stats) {
+    int rc;
+    if ((rc = check_camera(c, cam))) return rc;
+    if (!o) return fail(c, NERF_ERR_INVALID, "opts is NULL");
+    if (!d_out) return fail(c, NERF_ERR_INVALID, "output pointer is NULL");
+    if (o->n_coarse <= 0) return fail(c, NERF_ERR_INVALID, "coarse samples per ray must be greater than 0"); // src/lib.rs:483-486
+    if (o->n_fine < 0) return fail(c, NERF_ERR_INVALID, "fine samples per ray must be >= 0");
+    for (int r : o->reserved) if (r != 0) return fail(c, NERF_ERR_INVALID, "reserved option fields must be 0");
+    if (!c->net[NERF_NET_COARSE].loaded) return fail(c, NERF_ERR_STATE, "coarse network not loaded");
+    if (!o->coarse_only && !c->net[NERF_NET_FINE].loaded) return fail(c, NERF_ERR_STATE, "fine network not loaded");
+    const int s = o->ssaa > 1 ? o->ssaa : 1;
+    int x0 = 0, y0 = 0, cw = cam->nx, ch = cam->ny;
+    if (o->crop_w > 0 || o->crop_h > 0) { x0 = o->crop_x0; y0 = o->crop_y0; cw = o->crop_w; ch = o->crop_h; }
+    if (cw <= 0 || ch <= 0 || x0 < 0 || y0 < 0 || x0 + cw > cam->nx || y0 + ch > cam->ny)
+        return fail(c, NERF_ERR_INVALID, "crop window outside the frame");
+    const int nc = o->n_coarse;
+    // sample_importance returns nothing for count == 0 or < 3 coarse samples (src/lib.rs:295-297): the fine net
+    // then runs on the coarse samples only
+    const int nf = (o->coarse_only || o->n_fine == 0 || nc < 3) ? 0 : o->n_fine;
+    const int M = nc + nf;
+    if ((size_t)M * 7 * 4 * sizeof(float) > 160 * 1024) return fail(c, NERF_ERR_INVALID, "too many samples per ray for the compositing kernel");
+    const int RW = cw * s, RH = ch * s, RX0 = x0 * s, RY0 = y0 * s;
+    const size_t rows_per_pass = std::max<size_t>(1, std::min<size_t>(RH, c->max_rays_per_pass / (size_t)RW));
+    if ((rc = ensure_workspace(c, rows_per_pass * RW, nc, M))) return rc;
+    float *ray_out = d_out;
+    if (s > 1) {
+        if ((rc = ensure_bytes(c, (void **)&c->d_rayfb, &c->rayfb_floats, (size_t)RW * RH * 3 * sizeof(float)))) return rc;
+        ray_out = c->d_rayfb;
+    }
+    recycle_render(c);
+    recycle_dominant(c, 4096); // bound the backlog if the caller never queries
+    const bool timing = true;
+    RayGenArgs g = make_raygen(*cam, s);
+    const DevNet &NC = c->net[NERF_NET_COARSE], &NF = c->net[NERF_NET_FINE];
+    uint32_t passes = 0;
+    for (int row = 0; row < RH; row += (int)rows_per_pass, ++passes) {
+        const int rows = std::min<int>((int)rows_per_pass, RH - row);
+        const int n_rays = rows * RW;
+        g.n_rays = n_rays; g.rx0 = RX0; g.ry0 = RY0 + row; g.rw = RW;
+        {
+            Timed t(c, st, 2, 0, timing);
+            HIP_TRY(c, launch_ray_dirs(g, c->d_dirs, st));
+            HIP_TRY(c, launch_stratified(g, nc, cam->near_, cam->far_, o->seed, c->d_tc, st));
+            t.done(c->last_render);
+        }
+        MlpArgs a{};
+        a.mode = MLP_MODE_RAYS;
+        a.ray_dirs = c->d_dirs;
+        a.origin[0] = cam->pos[0]; a.origin[1] = cam->pos[1]; a.origin[2] = cam->pos[2];
+        // coarse network: sigma only unless its colours are composited (reference discards them, src/lib.rs:404)
+        a.wstream = NC.wstream; a.small_params = NC.small;
+        a.n_points = n_rays * nc; a.samples_per_ray = nc; a.t = c->d_tc;
+        a.sigma_out = c->d_sc; a.rgb_out = c->d_rgbc;
+        {
+            Timed t(c, st, o->coarse_only ? 1 : 0, (uint64_t)a.n_points, timing);
+            HIP_TRY(c, nerf_mlp_launch(a, o->coarse_only != 0, c->n_cus, st));
+            t.done(c->last_render);
+        }
+        float *pass_out = ray_out + (size_t)row * RW * 3;
+        CompositeArgs ca{};
+        ca.n_rays = n_rays; ca.far_ = cam->far_; ca.out = pass_out;
+        if (o->coarse_only) {
+            ca.n = nc; ca.t = c->d_tc; ca.sigma = c->d_sc; ca.rgb = c->d_rgbc;
+            Timed t(c, st, 2, 0, timing);
+            HIP_TRY(c, launch_composite(ca, st));
+            t.done(c->last_render);
+            continue;
+        }
+        const float *t_fine = c->d_tc;
+        if (nf > 0) {
+            ResampleArgs ra{};
+            ra.g = g; ra.n_rays = n_rays; ra.nc = nc; ra.nf = nf; ra.far_ = cam->far_;
+            ra.seed_lo = (uint32_t)o->seed; ra.seed_hi = (uint32_t)(o->seed >> 32);
+            ra.t_coarse = c->d_tc; ra.sigma_coarse = c->d_sc; ra.t_fine = c->d_tf;
+            Timed t(c, st, 2, 0, timing);
+            HIP_TRY(c, launch_resample(ra, st));
+            t.done(c->last_render);
+            t_fine = c->d_tf;
+        }
+        a.wstream = NF.wstream; a.small_params = NF.small;
+        a.n_points = n_rays * M; a.samples_per_ray = M; a.t = t_fine;
+        a.sigma_out = c->d_sf; a.rgb_out = c->d_rgbf;
+        {
+            Timed t(c, st, 1, (uint64_t)a.n_points, timing);
+            HIP_TRY(c, nerf_mlp_launch(a, true, c->n_cus, st));
+            t.done(c->last_render);
+        }
+        ca.n = M; ca.t = t_fine; ca.sigma = c->d_sf; ca.rgb = c->d_rgbf;
+        {
+            Timed t(c, st, 2, 0, timing);
+            HIP_TRY(c, launch_composite(ca, st));
+            t.done(c->last_render);
+        }
+    }
+    if (s > 1) {
+        Timed t(c, st, 2, 0, timing);
+        HIP_TRY(c, launch_box_downsample(c->d_rayfb, d_out, cw, ch, s, st));
+        t.done(c->last_render);
+    }
+    // the dominant-kernel events also feed nerf_kernel_time_query (ownership: see recycle_render)
+    for (const auto &p : c->last_render)
+        if (p.kind == 1) c->dominant.push_back(p);
+    if (stats) {
+        HIP_TRY(c, hipStreamSynchronize(st));
+        memset(stats, 0, sizeof *stats);
+        stats->n_rays = (uint64_t)RW * RH;
+        stats->n_passes = passes;
+        for (const auto &p : c->last_render) {
+            float ms = 0.f;
+            HIP_TRY(c, hipEventElapsedTime(&ms, p.a, p.b));
+            if (p.kind == 0) { stats->ms_coarse_mlp += ms; stats->n_coarse_points += p.points; stats->n_mlp_launches++; }
+            else if (p.kind == 1) {
+                stats->n_mlp_launches++;
+                if (o->coarse_only) { stats->ms_coarse_mlp += ms; stats->n_coarse_points += p.points; }
+                else { stats->ms_fine_mlp += ms; stats->n_fine_points += p.points; }
+            } else stats->ms_other += ms;
+        }
+        if (!c->last_render.empty()) {
+            float ms = 0.f;
+            HIP_TRY(c, hipEventElapsedTime(&ms, c->last_render.front().a, c->last_render.back().b));
+            stats->ms_total = ms;
+        }
+    }
+    return NERF_OK;
+}
+
+} // namespace
+
+// ================================================================================================
+// extern "C"
+// ================================================================================================
+extern "C" {
+
+int nerf_abi_version(void) { return 1; }
+
+const char *nerf_last_error(const nerf_ctx *ctx) { return ctx ? ctx->err.c_str() : g_err.c_str(); }
+
+int nerf_create(int device_id, nerf_ctx **out) {
+    if (!out) return fail(nullptr, NERF_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(nullptr, NERF_ERR_HIP, std::string("no HIP device available (") + hipGetErrorString(e) + "); libnerf_mi355x has no CPU fallback");
+    if (device_id < 0 || device_id >= n) return fail(nullptr, NERF_ERR_INVALID, "device_id out of range");
+    HIP_TRY(nullptr, hipSetDevice(device_id));
+    hipDeviceProp_t prop;
+    HIP_TRY(nullptr, hipGetDeviceProperties(&prop, device_id));
+    std::string arch = prop.gcnArchName;
+    if (arch.rfind("gfx950", 0) != 0)
+        return fail(nullptr, NERF_ERR_HIP, "device is " + arch + ", this library is built for gfx950 (MI355X) only");
+    nerf_ctx *c = new nerf_ctx();
+    c->device = device_id;
+    c->n_cus = prop.multiProcessorCount;
+    c->arch = arch;
+    if (const char *env = getenv("NERF_MAX_RAYS_PER_PASS")) {
+        const long long v = atoll(env);
+        if (v > 0) c->max_rays_per_pass = (size_t)v;
+    }
+    hipError_t e1 = nerf_mlp_init();
+    hipError_t e2 = e1 == hipSuccess ? sampling_init() : e1;
+    hipError_t e3 = e2 == hipSuccess ? hipStreamCreate(&c->stream) : e2;
+    if (e3 != hipSuccess) {
+        const std::string m = std::string("context initialisation failed: ") + hipGetErrorString(e3);
+        delete c;
+        return fail(nullptr, NERF_ERR_HIP, m);
+    }
+    *out = c;
+    return NERF_OK;
+}
+
+void nerf_destroy(nerf_ctx *c) {
+    if (!c) return;
+    DeviceGuard dg(c->device);
+    (void)hipDeviceSynchronize();
+    for (auto &n : c->net) { if (n.wstream) (void)hipFree(n.wstream); if (n.small) (void)hipFree(n.small); }
+    float *ptrs[] = {c->d_dirs, c->d_tc, c->d_sc, c->d_rgbc, c->d_tf, c->d_sf, c->d_rgbf, c->d_rayfb, c->d_out};
+    for (float *p : ptrs) if (p) (void)hipFree(p);
+    if (c->d_scratch) (void)hipFree(c->d_scratch);
+    recycle_render(c);
+    recycle_dominant(c, 0);
+    for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int nerf_device_info(const nerf_ctx *c, int *n_cus, char *arch_name, size_t len) {
+    if (!c) return fail(nullptr, NERF_ERR_INVALID, "ctx is NULL");
+    if (n_cus) *n_cus = c->n_cus;
+    if (arch_name && len) snprintf(arch_name, len, "%s", c->arch.c_str());
+    return NERF_OK;
+}
+
+int nerf_load_network_dir(nerf_ctx *c, int which, const char *dir) {
+    if (!c) return fail(nullptr, NERF_ERR_INVALID, "ctx is NULL");
+    if (which != NERF_NET_COARSE && which != NERF_NET_FINE) return fail(c, NERF_ERR_INVALID, "which must be NERF_NET_COARSE or NERF_NET_FINE");
+    if (!dir) return fail(c, NERF_ERR_INVALID, "dir is NULL");
+    DeviceGuard dg(c->device);
+    std::map<std::string, Tensor> params;
+    std::string err;
+    int rc = read_tensor_dir(dir, params, err);
+    if (rc) return fail(c, rc, err);
+    HostNet hn;
+    rc = assemble_net(params, hn, err);
+    if (rc) return fail(c, rc, err);
+    return upload_net(c, which, hn);
+}
+
+int nerf_load_network_tensors(nerf_ctx *c, int which, int n, const char *const *names, const int64_t *dims,
+                              const float *const *data) {
+    if (!c) return fail(nullptr, NERF_ERR_INVALID, "ctx is NULL");
+    if (which != NERF_NET_COARSE && which != NERF_NET_FINE) return fail(c, NERF_ERR_INVALID, "which must be NERF_NET_COARSE or NERF_NET_FINE");
+    if (n < 0 || (n > 0 && (!names || !dims || !data))) return fail(c, NERF_ERR_INVALID, "bad tensor table");
+    DeviceGuard dg(c->device);
+    std::map<std::string, Tensor> params;
+    for (int i = 0; i < n; ++i) {
+        if (!names[i] || !data[i] || dims[2 * i] < 0 || dims[2 * i + 1] < 0) return fail(c, NERF_ERR_INVALID, "bad tensor table entry");
+        Tensor t;
+        size_t cnt = (size_t)dims[2 * i];
+        t.dims.push_back(dims[2 * i]);
+        if (dims[2 * i + 1] > 0) { t.dims.push_back(dims[2 * i + 1]); cnt *= (size_t)dims[2 * i + 1]; }
+        t.data.assign(data[i], data[i] + cnt);
+        params[names[i]] = std::move(t);
+    }
+    HostNet hn;
+    std::string err;
+    const int rc = assemble_net(params, hn, err);
+    if (rc) return fail(c, rc, err);
+    return upload_net(c, which, hn);
+}
+
+int nerf_check_network_dir(const char *dir) {
+    if (!dir) return fail(nullptr, NERF_ERR_INVALID, "dir is NULL");
+    std::map<std::string, Tensor> params;
+    std::string err;
+    int rc = read_tensor_dir(dir, params, err);
+    if (rc) return fail(nullptr, rc, err);
+    HostNet hn;
+    rc = assemble_net(params, hn, err);
+    if (rc) return fail(nullptr, rc, err);
+    return NERF_OK;
+}
+
+int nerf_debug_pack_network_dir(const char *dir, float *wstream, size_t wstream_cap, float *small, size_t small_cap,
+                                size_t *wstream_len, size_t *small_len) {
+    if (!dir) return fail(nullptr, NERF_ERR_INVALID, "dir is NULL");
+    std::map<std::string, Tensor> params;
+    std::string err;
+    int rc = read_tensor_dir(dir, params, err);
+    if (rc) return fail(nullptr, rc, err);
+    HostNet hn;
+    rc = assemble_net(params, hn, err);
+    if (rc) return fail(nullptr, rc, err);
+    std::vector<float> ws, sm;
+    pack_network(hn, ws, sm);
+    if (wstream_len) *wstream_len = ws.size();
+    if (small_len) *small_len = sm.size();
+    if (wstream) { if (wstream_cap < ws.size()) return fail(nullptr, NERF_ERR_INVALID, "wstream buffer too small"); memcpy(wstream, ws.data(), ws.size() * sizeof(float)); }
+    if (small) { if (small_cap < sm.size()) return fail(nullptr, NERF_ERR_INVALID, "small buffer too small"); memcpy(small, sm.data(), sm.size() * sizeof(float)); }
+    return NERF_OK;
+}
+
+int nerf_forward_batch_device(nerf_ctx *c, int which, const float *d_pts, const float *d_dirs, size_t n, float *d_rgb,
+                              float *d_sigma, void *stream) {
+    if (!c) return fail(nullptr, NERF_ERR_INVALID, "ctx is NULL");
+    if (which != NERF_NET_COARSE && which != NERF_NET_FINE) return fail(c, NERF_ERR_INVALID, "which must be NERF_NET_COARSE or NERF_NET_FINE");
+    if (n == 0) return NERF_OK; // src/network.rs:199-201
+    if (!d_pts || !d_dirs || !d_rgb || !d_sigma) return fail(c, NERF_ERR_INVALID, "NULL buffer");
+    if (n > (size_t)0x7fffff00) return fail(c, NERF_ERR_INVALID, "batch too large (n must fit in int32)");
+    if (!c->net[which].loaded) return fail(c, NERF_ERR_STATE, "network not loaded");
+    DeviceGuard dg(c->device);
+    MlpArgs a{};
+    a.mode = MLP_MODE_POINTS;
+    a.wstream = c->net[which].wstream; a.small_params = c->net[which].small;
+    a.n_points = (int)n; a.pts_soa = d_pts; a.dirs_aos = d_dirs; a.sigma_out = d_sigma; a.rgb_out = d_rgb;
+    HIP_TRY(c, nerf_mlp_launch(a, true, c->n_cus, (hipStream_t)stream));
+    return NERF_OK;
+}
+
+int nerf_forward_batch(nerf_ctx *c, int which, const float *pts, const float *dirs, size_t n, float *rgb, float *sigma) {
+    if (!c) return fail(nullptr, NERF_ERR_INVALID, "ctx is NULL");
+    if (n == 0) return NERF_OK;
+    if (!pts || !dirs || !rgb || !sigma) return fail(c, NERF_ERR_INVALID, "NULL buffer");
+    DeviceGuard dg(c->device);
+    int rc;
+    if ((rc = ensure_bytes(c, &c->d_scratch, &c->scratch_bytes, n * 10 * sizeof(float)))) return rc;
+    float *d_pts = (float *)c->d_scratch, *d_dirs = d_pts + 3 * n, *d_rgb = d_dirs + 3 * n, *d_sig = d_rgb + 3 * n;
+    HIP_TRY(c, hipMemcpyAsync(d_pts, pts, 3 * n * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(d_dirs, dirs, 3 * n * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    if ((rc = nerf_forward_batch_device(c, which, d_pts, d_dirs, n, d_rgb, d_sig, c->stream))) return rc;
+    HIP_TRY(c, hipMemcpyAsync(rgb, d_rgb, 3 * n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(sigma, d_sig, n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return NERF_OK;
+}
+
+int nerf_render_image_device(nerf_ctx *c, const nerf_camera *cam, const nerf_render_opts *opts, float *d_rgb_out,
+                             void *stream, nerf_stats *stats) {
+    if (!c) return fail(nullptr, NERF_ERR_INVALID, "ctx is NULL");
+    DeviceGuard dg(c->device);
+    return render_device(c, cam, opts, d_rgb_out, (hipStream_t)stream, stats);
+}
+
+int nerf_render_image(nerf_ctx *c, const nerf_camera *cam, const nerf_render_opts *opts, float *rgb_out, nerf_stats *stats) {
+    if (!c) return fail(nullptr, NERF_ERR_INVALID, "ctx is NULL");
+    if (!rgb_out) return fail(c, NERF_ERR_INVALID, "output pointer is NULL");
+    int rc;
+    if ((rc = check_camera(c, cam))) return rc;
+    if (!opts) return fail(c, NERF_ERR_INVALID, "opts is NULL");
+    DeviceGuard dg(c->device);
+    const bool crop = opts->crop_w > 0 || opts->crop_h > 0;
+    const long long w = crop ? opts->crop_w : cam->nx, h = crop ? opts->crop_h : cam->ny;
+    if (w <= 0 || h <= 0) return fail(c, NERF_ERR_INVALID, "crop window outside the frame");
+    const size_t bytes = (size_t)w * h * 3 * sizeof(float);
+    if ((rc = ensure_bytes(c, (void **)&c->d_out, &c->out_floats, bytes))) return rc;
+    if ((rc = render_device(c, cam, opts, c->d_out, c->stream, stats))) return rc;
+    HIP_TRY(c, hipMemcpyAsync(rgb_out, c->d_out, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return NERF_OK;
+}
+
+int nerf_kernel_time_query(nerf_ctx *c, double *ms, uint64_t *points, uint32_t *n_launches, int reset) {
+    if (!c) return fail(nullptr, NERF_ERR_INVALID, "ctx is NULL");
+    DeviceGuard dg(c->device);
+    double tot = 0.0; uint64_t pts = 0; uint32_t nl = 0;
+    for (const auto &p : c->dominant) {
+        HIP_TRY(c, hipEventSynchronize(p.b));
+        float t = 0.f;
+        HIP_TRY(c, hipEventElapsedTime(&t, p.a, p.b));
+        tot += t; pts += p.points; ++nl;
+    }
+    if (ms) *ms = tot;
+    if (points) *points = pts;
+    if (n_launches) *n_launches = nl;
+    if (reset) {
+        // last_render may still list these pairs (kind 1); it never recycles them, and they are not read again
+        for (auto &p : c->last_render) if (p.kind == 1) p.kind = 3;
+        c->last_render.erase(std::remove_if(c->last_render.begin(), c->last_render.end(), [](const EvPair &p) { return p.kind == 3; }), c->last_render.end());
+        recycle_dominant(c, 0);
+    }
+    return NERF_OK;
+}
+
+int nerf_camera_from_json(const char *path, int width, int height, nerf_camera *out) {
+    if (!path || !out) return fail(nullptr, NERF_ERR_INVALID, "NULL argument");
+    std::string err;
+    const int rc = camera_from_json(path, width, height, out, err);
+    return rc ? fail(nullptr, rc, err) : NERF_OK;
+}
+
+int nerf_camera_from_values(float near_, float far_, const float origin[3], const float forward[3], const float up[3],
+                            const float hwf[3], int width, int height, nerf_camera *out) {
+    if (!origin || !forward || !up || !hwf || !out) return fail(nullptr, NERF_ERR_INVALID, "NULL argument");
+    camera_from_values(near_, far_, origin, forward, up, hwf, width, height, out);
+    return NERF_OK;
+}
+
+int nerf_save_ppm(const char *path, int width, int height, const float *rgb) {
+    if (!path || !rgb) return fail(nullptr, NERF_ERR_INVALID, "NULL argument");
+    std::string err;
+    const int rc = save_ppm(path, width, height, rgb, err);
+    return rc ? fail(nullptr, rc, err) : NERF_OK;
+}
+
+void nerf_quantize_rgb8(const float *rgb, size_t n_pixels, uint8_t *out) { quantize_rgb8(rgb, n_pixels, out); }
+
+// ---- stage entry points ------------------------------------------------------------------------------------
+static int stage_rect(nerf_ctx *c, const nerf_camera *cam, int x0, int y0, int w, int h, RayGenArgs &g) {
+    int rc;
+    if ((rc = check_camera(c, cam))) return rc;
+    if (w <= 0 || h <= 0 || x0 < 0 || y0 < 0 || x0 + w > cam->nx || y0 + h > cam->ny) return fail(c, NERF_ERR_INVALID, "rectangle outside the frame");
+    g = make_raygen(*cam, 1);
+    g.n_rays = w * h; g.rx0 = x0; g.ry0 = y0; g.rw = w;
+    return NERF_OK;
+}
+
+int nerf_stage_ray_dirs(nerf_ctx *c, const nerf_camera *cam, int x0, int y0, int w, int h, int normalize, float *out) {
+    if (!c) return fail(nullptr, NERF_ERR_INVALID, "ctx is NULL");
+    if (!out) return fail(c, NERF_ERR_INVALID, "NULL buffer");
+    DeviceGuard dg(c->device);
+    RayGenArgs g; int rc;
+    if ((rc = stage_rect(c, cam, x0, y0, w, h, g))) return rc;
+    g.normalize = normalize ? 1 : 0;
+    const size_t bytes = (size_t)g.n_rays * 3 * sizeof(float);
+    if ((rc = ensure_bytes(c, &c->d_scratch, &c->scratch_bytes, bytes))) return rc;
+    HIP_TRY(c, launch_ray_dirs(g, (float *)c->d_scratch, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(out, c->d_scratch, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return NERF_OK;
+}
+
+int nerf_stage_stratified(nerf_ctx *c, const nerf_camera *cam, int x0, int y0, int w, int h, int count, uint64_t seed, float *out) {
+    if (!c) return fail(nullptr, NERF_ERR_INVALID, "ctx is NULL");
+    if (!out) return fail(c, NERF_ERR_INVALID, "NULL buffer");
+    if (count <= 0) return NERF_OK; // src/lib.rs:235-237
+    DeviceGuard dg(c->device);
+    RayGenArgs g; int rc;
+    if ((rc = stage_rect(c, cam, x0, y0, w, h, g))) return rc;
+    const size_t bytes = (size_t)g.n_rays * count * sizeof(float);
+    if ((rc = ensure_bytes(c, &c->d_scratch, &c->scratch_bytes, bytes))) return rc;
+    HIP_TRY(c, launch_stratified(g, count, cam->near_, cam->far_, seed, (float *)c->d_scratch, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(out, c->d_scratch, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return NERF_OK;
+}
+
+int nerf_stage_resample(nerf_ctx *c, size_t n_rays, int nc, int nf, float far_, uint64_t seed, const uint32_t *pixel_index,
+                        const float *t_coarse, const float *sigma_coarse, const float *u, float *w_out, float *cdf_out,
+                        float *t_new_out, float *t_fine_out) {
+    if (!c) return fail(nullptr, NERF_ERR_INVALID, "ctx is NULL");
+    if (n_rays == 0) return NERF_OK;
+    if (!t_coarse || !sigma_coarse || !t_fine_out) return fail(c, NERF_ERR_INVALID, "NULL buffer");
+    if (nc < 3 || nf <= 0) return fail(c, NERF_ERR_INVALID, "resample needs nc >= 3 and nf > 0 (src/lib.rs:295-297)");
+    if (!u && !pixel_index) return fail(c, NERF_ERR_INVALID, "either u or pixel_index must be given");
+    if (resample_lds_bytes(nc, nf) > 160 * 1024 || n_rays > 0x7fffffff / (size_t)(nc + nf)) return fail(c, NERF_ERR_INVALID, "too many samples");
+    DeviceGuard dg(c->device);
+    const size_t R = n_rays, M = (size_t)nc + nf;
+    // layout in scratch (floats): tc, sc, u, w, cdf, tnew, tfine, pix
+    const size_t o_tc = 0, o_sc = o_tc + R * nc, o_u = o_sc + R * nc, o_w = o_u + R * nf, o_cdf = o_w + R * nc,
+                 o_tn = o_cdf + R * (nc - 1), o_tf = o_tn + R * nf, o_px = o_tf + R * M, total = o_px + R;
+    int rc;
+    if ((rc = ensure_bytes(c, &c->d_scratch, &c->scratch_bytes, total * sizeof(float)))) return rc;
+    float *d = (float *)c->d_scratch;
+    HIP_TRY(c, hipMemcpyAsync(d + o_tc, t_coarse, R * nc * 4, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(d + o_sc, sigma_coarse, R * nc * 4, hipMemcpyHostToDevice, c->stream));
+    if (u) HIP_TRY(c, hipMemcpyAsync(d + o_u, u, R * nf * 4, hipMemcpyHostToDevice, c->stream));
+    if (pixel_index) HIP_TRY(c, hipMemcpyAsync(d + o_px, pixel_index, R * 4, hipMemcpyHostToDevice, c->stream));
+    ResampleArgs ra{};
+    ra.n_rays = (int)R; ra.nc = nc; ra.nf = nf; ra.far_ = far_;
+    ra.seed_lo = (uint32_t)seed; ra.seed_hi = (uint32_t)(seed >> 32);
+    ra.t_coarse = d + o_tc; ra.sigma_coarse = d + o_sc; ra.t_fine = d + o_tf;
+    ra.pixel_index = pixel_index ? (const uint32_t *)(d + o_px) : nullptr;
+    ra.u_in = u ? d + o_u : nullptr;
+    ra.w_out = d + o_w; ra.cdf_out = d + o_cdf; ra.t_new_out = d + o_tn;
+    ra.g.rw = 1; ra.g.rnx = 1; // unused when pixel_index/u are given
+    HIP_TRY(c, launch_resample(ra, c->stream));
+    if (w_out) HIP_TRY(c, hipMemcpyAsync(w_out, d + o_w, R * nc * 4, hipMemcpyDeviceToHost, c->stream));
+    if (cdf_out) HIP_TRY(c, hipMemcpyAsync(cdf_out, d + o_cdf, R * (nc - 1) * 4, hipMemcpyDeviceToHost, c->stream));
+    if (t_new_out) HIP_TRY(c, hipMemcpyAsync(t_new_out, d + o_tn, R * nf * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(t_fine_out, d + o_tf, R * M * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return NERF_OK;
+}
+
+int nerf_stage_integrate(nerf_ctx *c, size_t n_rays, int n, float far_, const float *rgb, const float *sigma, const float *t,
+                         float *rgb_out, float *w_out) {
+    if (!c) return fail(nullptr, NERF_ERR_INVALID, "ctx is NULL");
+    if (n_rays == 0) return NERF_OK;
+    if (!rgb_out) return fail(c, NERF_ERR_INVALID, "NULL buffer");
+    if (n == 0) { memset(rgb_out, 0, n_rays * 3 * sizeof(float)); return NERF_OK; } // src/lib.rs:178-180
+    if (n < 0 || !rgb || !sigma || !t) return fail(c, NERF_ERR_INVALID, "bad argument");
+    if (composite_lds_bytes(n) > 160 * 1024 || n_rays > 0x7fffffff / (size_t)n) return fail(c, NERF_ERR_INVALID, "too many samples");
+    DeviceGuard dg(c->device);
+    const size_t R = n_rays, N = (size_t)n;
+    const size_t o_t = 0, o_s = o_t + R * N, o_c = o_s + R * N, o_w = o_c + 3 * R * N, o_o = o_w + R * N, total = o_o + 3 * R;
+    int rc;
+    if ((rc = ensure_bytes(c, &c->d_scratch, &c->scratch_bytes, total * sizeof(float)))) return rc;
+    float *d = (float *)c->d_scratch;
+    HIP_TRY(c, hipMemcpyAsync(d + o_t, t, R * N * 4, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(d + o_s, sigma, R * N * 4, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(d + o_c, rgb, 3 * R * N * 4, hipMemcpyHostToDevice, c->stream));
+    CompositeArgs ca{};
+    ca.n_rays = (int)R; ca.n = n; ca.far_ = far_; ca.t = d + o_t; ca.sigma = d + o_s; ca.rgb = d + o_c; ca.out = d + o_o; ca.w_out = d + o_w;
+    HIP_TRY(c, launch_composite(ca, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(rgb_out, d + o_o, 3 * R * 4, hipMemcpyDeviceToHost, c->stream));
+    if (w_out) HIP_TRY(c, hipMemcpyAsync(w_out, d + o_w, R * N * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return NERF_OK;
+}
+
+} // extern "C"

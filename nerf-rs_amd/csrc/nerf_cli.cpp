@@ -1,0 +1,87 @@
+// nerf_cli.cpp -- the MI355X counterpart of `cargo run --release` (reference src/main.rs:1-3 ->
+// render_cli_image, src/lib.rs:647-677): load lego_rust/{coarse,fine}, build the camera from
+// tf_reference_samples.json, render, print the same facts, write output.ppm.  Plain C++ over the C ABI
+// (include/nerf_mi355x.h) -- exactly what a Rust main.rs would do through the extern "C" block of INTEGRATION.md.
+//
+// With no flags it reproduces the reference's run: 256x256, 64 coarse + 128 fine samples, ./output.ppm.
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/nerf_mi355x.h"
+
+static void usage(const char *argv0) {
+    fprintf(stderr,
+            "usage: %s [--scene DIR] [--width W] [--height H] [--coarse N] [--fine N] [--seed S] [--ssaa S]\n"
+            "          [--coarse-only] [--crop X0,Y0,W,H] [--device ID] [--frames K] [--out FILE.ppm]\n"
+            "defaults: --scene lego_rust --width 256 --height 256 --coarse 64 --fine 128 --out output.ppm\n",
+            argv0);
+}
+
+int main(int argc, char **argv) {
+    std::string scene = getenv("NERF_SCENE_DIR") ? getenv("NERF_SCENE_DIR") : "lego_rust";
+    std::string out = "output.ppm";
+    int width = 256, height = 256, device = 0, frames = 1; // src/lib.rs:657-658
+    nerf_render_opts opts;
+    memset(&opts, 0, sizeof opts);
+    opts.n_coarse = 64; opts.n_fine = 128; // default_sample_counts, src/lib.rs:603-612
+    for (int i = 1; i < argc; ++i) {
+        const std::string a = argv[i];
+        auto next = [&]() -> const char * { if (i + 1 >= argc) { usage(argv[0]); exit(2); } return argv[++i]; };
+        if (a == "--scene") scene = next();
+        else if (a == "--width") width = atoi(next());
+        else if (a == "--height") height = atoi(next());
+        else if (a == "--coarse") opts.n_coarse = atoi(next());
+        else if (a == "--fine") opts.n_fine = atoi(next());
+        else if (a == "--seed") opts.seed = strtoull(next(), nullptr, 10);
+        else if (a == "--ssaa") opts.ssaa = atoi(next());
+        else if (a == "--coarse-only") opts.coarse_only = 1;
+        else if (a == "--device") device = atoi(next());
+        else if (a == "--frames") frames = atoi(next());
+        else if (a == "--out") out = next();
+        else if (a == "--crop") {
+            if (sscanf(next(), "%d,%d,%d,%d", &opts.crop_x0, &opts.crop_y0, &opts.crop_w, &opts.crop_h) != 4) { usage(argv[0]); return 2; }
+        } else { usage(argv[0]); return a == "--help" || a == "-h" ? 0 : 2; }
+    }
+
+    nerf_ctx *ctx = nullptr;
+    if (nerf_create(device, &ctx)) { fprintf(stderr, "error: %s\n", nerf_last_error(nullptr)); return 1; }
+    if (nerf_load_network_dir(ctx, NERF_NET_COARSE, (scene + "/coarse").c_str()) ||
+        nerf_load_network_dir(ctx, NERF_NET_FINE, (scene + "/fine").c_str())) {
+        fprintf(stderr, "error: %s\n", nerf_last_error(ctx));
+        return 1;
+    }
+    nerf_camera cam;
+    if (nerf_camera_from_json((scene + "/tf_reference_samples.json").c_str(), width, height, &cam)) {
+        fprintf(stderr, "error: %s\n", nerf_last_error(nullptr));
+        return 1;
+    }
+    printf("Rendering with %d coarse samples and %d fine samples per ray\n", opts.n_coarse, opts.n_fine); // :660-663
+    const int ow = opts.crop_w > 0 ? opts.crop_w : width, oh = opts.crop_h > 0 ? opts.crop_h : height;
+    std::vector<float> image((size_t)ow * oh * 3);
+    printf("Starting image rendering...\n"); // :667
+    nerf_stats st;
+    double best = 1e30;
+    for (int f = 0; f < frames; ++f) {
+        const auto t0 = std::chrono::steady_clock::now(); // Instant::now() :668
+        if (nerf_render_image(ctx, &cam, &opts, image.data(), &st)) { fprintf(stderr, "error: %s\n", nerf_last_error(ctx)); return 1; }
+        const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        best = secs < best ? secs : best;
+        printf("Rendering complete: %llu/%llu pixels (100.0%%)\n", (unsigned long long)ow * oh, (unsigned long long)ow * oh); // :559-562
+        printf("Rendering completed in %.2f seconds\n", secs); // :672-675
+    }
+    int n_cus = 0; char arch[64] = {0};
+    nerf_device_info(ctx, &n_cus, arch, sizeof arch);
+    const double flop_ray = opts.coarse_only ? opts.n_coarse * 1186816.0
+                                             : opts.n_coarse * 982528.0 + (double)(opts.n_coarse + opts.n_fine) * 1186816.0;
+    printf("device %s (%d CUs): %.0f rays/s (best of %d, host wall incl. D2H); device %.1f ms = coarse MLP %.1f + fine MLP %.1f + other %.1f; "
+           "%.1f%% of the 157.3 TFLOP/s fp32 MFMA roofline\n",
+           arch, n_cus, (double)st.n_rays / best, frames, st.ms_total, st.ms_coarse_mlp, st.ms_fine_mlp, st.ms_other,
+           100.0 * (double)st.n_rays * flop_ray / (st.ms_total * 1e-3) / 157.3e12);
+    if (nerf_save_ppm(out.c_str(), ow, oh, image.data())) { fprintf(stderr, "error: %s\n", nerf_last_error(nullptr)); return 1; } // :676
+    nerf_destroy(ctx);
+    return 0;
+}

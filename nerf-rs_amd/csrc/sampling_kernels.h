@@ -1,0 +1,51 @@
+// sampling_kernels.h -- launch interface of the sampling / integration kernels (internal).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+// A pass renders the rectangle [ry0, ry0+rh) x [rx0, rx0+rw) of the (rny x rnx) ray grid; ray r of the pass is
+// (ry0 + r / rw, rx0 + r % rw); its RNG pixel index is row * rnx + col.
+struct RayGenArgs {
+    int n_rays;
+    int rx0, ry0, rw, rnx, rny;
+    float half;      // 0.5: pixel centre (src/lib.rs:221-222)
+    int normalize;   // 1: dir.normalize() (src/lib.rs:371)
+    float sx, sy;    // tan(alpha_width), tan(alpha_height)
+    float r[3], u[3], f[3]; // orthonormal basis (src/lib.rs:216-218), computed on the host
+};
+
+struct ResampleArgs {
+    RayGenArgs g;
+    int n_rays, nc, nf;
+    float far_;
+    uint32_t seed_lo, seed_hi;
+    const float *t_coarse;     // n_rays x nc
+    const float *sigma_coarse; // n_rays x nc
+    float *t_fine;             // n_rays x (nc + nf), ascending
+    // stage-test hooks (all optional)
+    const uint32_t *pixel_index; // n_rays: overrides the rectangle-derived pixel index
+    const float *u_in;           // n_rays x nf: overrides the Philox uniforms
+    float *w_out;                // n_rays x nc
+    float *cdf_out;              // n_rays x (nc - 1)
+    float *t_new_out;            // n_rays x nf (unsorted draws)
+};
+
+struct CompositeArgs {
+    int n_rays, n;
+    float far_;
+    const float *t;     // n_rays x n
+    const float *sigma; // n_rays x n
+    const float *rgb;   // n_rays x n x 3
+    float *out;         // n_rays x 3
+    float *w_out;       // optional n_rays x n
+};
+
+hipError_t sampling_init(void);
+hipError_t launch_ray_dirs(const RayGenArgs &a, float *dirs, hipStream_t st);
+hipError_t launch_stratified(const RayGenArgs &a, int count, float near_, float far_, uint64_t seed, float *t,
+                             hipStream_t st);
+hipError_t launch_resample(const ResampleArgs &a, hipStream_t st);
+hipError_t launch_composite(const CompositeArgs &a, hipStream_t st);
+hipError_t launch_box_downsample(const float *rays, float *out, int w, int h, int s, hipStream_t st);
+size_t resample_lds_bytes(int nc, int nf);
+size_t composite_lds_bytes(int n);

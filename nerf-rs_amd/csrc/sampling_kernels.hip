@@ -1,0 +1,259 @@
+// sampling_kernels.hip -- ray generation, stratified + hierarchical sampling, transmittance integration.
+//
+// gfx950 restatement of the non-MLP part of render_block (reference src/lib.rs:353-472):
+//   k_ray_dirs         Camera::get_ray_dir + normalize            (src/lib.rs:213-231, 367-373; src/vec3.rs:27-34)
+//   k_stratified       stratified_samples                          (src/lib.rs:233-248)
+//   k_resample         compute_weights + sample_importance + sort  (src/lib.rs:250-351, 414-420)
+//   k_composite        integrate_ray                               (src/lib.rs:176-195)
+//   k_box_downsample   SSAA box filter (extension)
+// All arithmetic is IEEE f32 without contraction (the file is built with -ffp-contract=off and HIP's default
+// correctly-rounded fp32 divide/sqrt), so ray directions and coarse sample positions are BIT-IDENTICAL to the
+// CPU path; the sequential f32 sums of the reference (pdf sum, cdf, transmittance, colour accumulation) are kept
+// in the reference's order.  These kernels are HBM/latency-bound bookkeeping (<1 % of a frame); the layout is one
+// wave per ray (lanes = samples), 4 rays per 256-thread workgroup.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "sampling_kernels.h"
+
+namespace {
+
+// Philox-4x32-10, key = seed, counter = (pixel_index, stream, k/4, 0); same stream as the CPU oracle.
+__device__ __forceinline__ void philox4x32(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint32_t c2,
+                                           uint32_t c3, uint32_t (&out)[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+__device__ __forceinline__ float u01(uint32_t x) { return (float)(x >> 9) * (1.0f / 8388608.0f); }
+
+// Intra-wave LDS hand-off: LDS instructions of one wave execute in issue order, so a compiler-level fence
+// (no instruction at wavefront scope) plus a scheduling barrier is all that is needed.
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+} // namespace
+
+// ---- ray directions: one thread per ray of the pass rectangle ---------------------------------------
+__global__ void k_ray_dirs(RayGenArgs a, float *__restrict__ dirs) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= a.n_rays) return;
+    const int i = a.ry0 + r / a.rw, j = a.rx0 + r % a.rw;
+    const float x = (((float)j + a.half) / (float)a.rnx) * 2.0f - 1.0f;
+    const float y = 1.0f - (((float)i + a.half) / (float)a.rny) * 2.0f;
+    const float xs = x * a.sx, ys = y * a.sy;
+    const float dx = (a.r[0] * xs + a.u[0] * ys) + a.f[0];
+    const float dy = (a.r[1] * xs + a.u[1] * ys) + a.f[1];
+    const float dz = (a.r[2] * xs + a.u[2] * ys) + a.f[2];
+    if (a.normalize) {
+        const float len = sqrtf(dx * dx + dy * dy + dz * dz);
+        dirs[3 * (size_t)r + 0] = dx / len; dirs[3 * (size_t)r + 1] = dy / len; dirs[3 * (size_t)r + 2] = dz / len;
+    } else {
+        dirs[3 * (size_t)r + 0] = dx; dirs[3 * (size_t)r + 1] = dy; dirs[3 * (size_t)r + 2] = dz;
+    }
+}
+
+// ---- stratified samples: one thread per (ray, group of 4 samples) -----------------------------------
+__global__ void k_stratified(RayGenArgs a, int count, float near_, float far_, uint32_t seed_lo, uint32_t seed_hi,
+                             float *__restrict__ t) {
+    const int quads = (count + 3) >> 2;
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (long long)a.n_rays * quads) return;
+    const int r = (int)(gid / quads), q = (int)(gid % quads);
+    const uint32_t pix = (uint32_t)((a.ry0 + r / a.rw) * a.rnx + (a.rx0 + r % a.rw));
+    uint32_t rnd[4];
+    philox4x32(seed_lo, seed_hi, pix, 0u, (uint32_t)q, 0u, rnd);
+    const float interval = (far_ - near_) / (float)count;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int k = 4 * q + e;
+        if (k < count) {
+            const float lower = near_ + (float)k * interval;
+            const float upper = lower + interval;
+            t[(size_t)r * count + k] = lower + (upper - lower) * u01(rnd[e]);
+        }
+    }
+}
+
+// ---- transmittance weights, shared by resample and composite ----------------------------------------
+// alpha[] in LDS -> w[] in LDS, sequential in sample order exactly as compute_weights (src/lib.rs:261-280).
+// Executed redundantly by every lane of the wave (wave-uniform control flow, LDS broadcast reads).
+__device__ __forceinline__ void weights_scan(const float *alpha, float *w, int n, int lane) {
+    float T = 1.0f;
+    int i = 0;
+    for (; i < n; ++i) {
+        const float al = alpha[i];
+        const float wi = T * al;
+        if (lane == 0) w[i] = wi;
+        T *= 1.0f - al;
+        if (T < 1e-4f) { ++i; break; }
+    }
+    for (int k = i + lane; k < n; k += 64) w[k] = 0.0f; // weights.extend(repeat(0.0)) :277
+}
+
+__device__ __forceinline__ float sample_alpha(const float *t, const float *sigma, int i, int n, float far_) {
+    float delta = (i + 1 < n) ? t[i + 1] - t[i] : far_ - t[i];
+    if (delta < 0.0f) delta = 0.0f;
+    return 1.0f - expf(-sigma[i] * delta);
+}
+
+// ---- hierarchical resampling: one wave per ray --------------------------------------------------------
+// LDS per wave (floats): t[nc] sigma[nc] alpha[nc] w[nc] cdf[nc] bins[nc] merged[nc+nf]
+__global__ __launch_bounds__(256) void k_resample(ResampleArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds_f[];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int ray = blockIdx.x * 4 + wv;
+    if (ray >= a.n_rays) return; // whole wave exits together; no block-level barrier below
+    const int nc = a.nc, nf = a.nf, M = nc + nf;
+    float *t = lds_f + (size_t)wv * (6 * nc + M);
+    float *sg = t + nc, *alpha = sg + nc, *w = alpha + nc, *cdf = w + nc, *bins = cdf + nc, *mg = bins + nc;
+
+    for (int i = lane; i < nc; i += 64) { t[i] = a.t_coarse[(size_t)ray * nc + i]; sg[i] = a.sigma_coarse[(size_t)ray * nc + i]; }
+    wave_sync();
+    for (int i = lane; i < nc; i += 64) alpha[i] = sample_alpha(t, sg, i, nc, a.far_);
+    wave_sync();
+    weights_scan(alpha, w, nc, lane);
+    wave_sync();
+    if (a.w_out) for (int i = lane; i < nc; i += 64) a.w_out[(size_t)ray * nc + i] = w[i];
+
+    // sample_importance (src/lib.rs:289-351); nc >= 3 and nf > 0 guaranteed by the host
+    const int m = nc - 2;
+    for (int i = lane; i < nc - 1; i += 64) bins[i] = 0.5f * (t[i] + t[i + 1]);
+    for (int i = lane; i < m; i += 64) { const float x = w[i + 1]; alpha[i] = (x > 0.0f ? x : 0.0f) + 1e-5f; } // adjusted
+    wave_sync();
+    float sum = 0.0f;
+    for (int i = 0; i < m; ++i) sum += alpha[i];                 // iter().sum(), sequential
+    wave_sync();
+    for (int i = lane; i < m; i += 64) alpha[i] = alpha[i] / sum;
+    wave_sync();
+    float cumulative = 0.0f;
+    for (int i = 0; i < m; ++i) { cumulative += alpha[i]; if (lane == 0) cdf[i + 1] = cumulative; }
+    if (lane == 0) { cdf[0] = 0.0f; cdf[m] = 1.0f; }             // :320, :326-328
+    wave_sync();
+    if (a.cdf_out) for (int i = lane; i <= m; i += 64) a.cdf_out[(size_t)ray * (nc - 1) + i] = cdf[i];
+
+    const uint32_t pix = a.pixel_index ? a.pixel_index[ray]
+                                       : (uint32_t)((a.g.ry0 + ray / a.g.rw) * a.g.rnx + (a.g.rx0 + ray % a.g.rw));
+    for (int s = lane; s < nf; s += 64) {
+        float u;
+        if (a.u_in) u = a.u_in[(size_t)ray * nf + s];
+        else { uint32_t rnd[4]; philox4x32(a.seed_lo, a.seed_hi, pix, 1u, (uint32_t)(s >> 2), 0u, rnd); u = u01(rnd[s & 3]); }
+        // first j with cdf[j] <= u < cdf[j+1] == largest j in [0,m-1] with cdf[j] <= u for a non-decreasing cdf
+        int lo = 0, hi = m - 1;
+        if (!(u >= cdf[0] && u < cdf[m])) lo = hi;                // no match: idx = adjusted.len() - 1 (:333)
+        while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (cdf[mid] <= u) lo = mid; else hi = mid - 1; }
+        const float cl = cdf[lo], cu = cdf[lo + 1];
+        float denom = cu - cl;
+        if (!(denom > 1e-6f)) denom = 1e-6f;
+        const float bl = bins[lo], bu = bins[lo + 1];
+        const float tt = (u - cl) / denom;
+        mg[nc + s] = bl + (bu - bl) * tt;
+    }
+    for (int i = lane; i < nc; i += 64) mg[i] = t[i];
+    wave_sync();
+    if (a.t_new_out) for (int s = lane; s < nf; s += 64) a.t_new_out[(size_t)ray * nf + s] = mg[nc + s];
+
+    // merged.sort_by(partial_cmp) (:419): rank sort, ties broken by original index (stable)
+    for (int e = lane; e < M; e += 64) {
+        const float v = mg[e];
+        int rank = 0;
+        for (int j = 0; j < M; ++j) { const float x = mg[j]; rank += (x < v || (x == v && j < e)) ? 1 : 0; }
+        a.t_fine[(size_t)ray * M + rank] = v;
+    }
+}
+
+// ---- compositing: one wave per ray -------------------------------------------------------------------
+// LDS per wave (floats): t[n] sigma[n] alpha[n] w[n] rgb[3n]
+__global__ __launch_bounds__(256) void k_composite(CompositeArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds_f[];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int ray = blockIdx.x * 4 + wv;
+    if (ray >= a.n_rays) return;
+    const int n = a.n;
+    float *t = lds_f + (size_t)wv * (7 * n);
+    float *sg = t + n, *alpha = sg + n, *w = alpha + n, *col = w + n;
+    for (int i = lane; i < n; i += 64) { t[i] = a.t[(size_t)ray * n + i]; sg[i] = a.sigma[(size_t)ray * n + i]; }
+    for (int i = lane; i < 3 * n; i += 64) col[i] = a.rgb[(size_t)ray * 3 * n + i];
+    wave_sync();
+    for (int i = lane; i < n; i += 64) alpha[i] = sample_alpha(t, sg, i, n, a.far_);
+    wave_sync();
+    weights_scan(alpha, w, n, lane);
+    wave_sync();
+    if (a.w_out) for (int i = lane; i < n; i += 64) a.w_out[(size_t)ray * n + i] = w[i];
+    float r = 0.0f, g = 0.0f, b = 0.0f, acc = 0.0f; // integrate_ray :185-194, sample order
+    for (int i = 0; i < n; ++i) {
+        const float wi = w[i];
+        r += col[3 * i] * wi; g += col[3 * i + 1] * wi; b += col[3 * i + 2] * wi;
+        acc += wi;
+    }
+    if (lane == 0) {
+        const float bg = 1.0f * (1.0f - acc);
+        float *o = a.out + 3 * (size_t)ray;
+        o[0] = r + bg; o[1] = g + bg; o[2] = b + bg;
+    }
+}
+
+// ---- SSAA box filter: out[i][j][c] = (sum over s x s sub-rays, row-major) * (1/(s*s)) -------------------
+__global__ void k_box_downsample(const float *__restrict__ rays, float *__restrict__ out, int w, int h, int s) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= w * h * 3) return;
+    const int c = idx % 3, j = (idx / 3) % w, i = idx / (3 * w);
+    const int RW = w * s;
+    float acc = 0.0f;
+    for (int di = 0; di < s; ++di)
+        for (int dj = 0; dj < s; ++dj) acc += rays[3 * ((size_t)(i * s + di) * RW + (j * s + dj)) + c];
+    out[idx] = acc * (1.0f / (float)(s * s));
+}
+
+// ---- launchers -----------------------------------------------------------------------------------------
+hipError_t launch_ray_dirs(const RayGenArgs &a, float *dirs, hipStream_t st) {
+    if (a.n_rays <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_ray_dirs, dim3((a.n_rays + 255) / 256), dim3(256), 0, st, a, dirs);
+    return hipGetLastError();
+}
+
+hipError_t launch_stratified(const RayGenArgs &a, int count, float near_, float far_, uint64_t seed, float *t,
+                             hipStream_t st) {
+    if (a.n_rays <= 0 || count <= 0) return hipSuccess;
+    const long long total = (long long)a.n_rays * ((count + 3) / 4);
+    hipLaunchKernelGGL(k_stratified, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a, count, near_, far_,
+                       (uint32_t)seed, (uint32_t)(seed >> 32), t);
+    return hipGetLastError();
+}
+
+size_t resample_lds_bytes(int nc, int nf) { return (size_t)4 * (6 * nc + nc + nf) * sizeof(float); }
+size_t composite_lds_bytes(int n) { return (size_t)4 * 7 * n * sizeof(float); }
+
+hipError_t sampling_init(void) {
+    hipError_t e = hipFuncSetAttribute((const void *)k_resample, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute((const void *)k_composite, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+}
+
+hipError_t launch_resample(const ResampleArgs &a, hipStream_t st) {
+    if (a.n_rays <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_resample, dim3((a.n_rays + 3) / 4), dim3(256), resample_lds_bytes(a.nc, a.nf), st, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_composite(const CompositeArgs &a, hipStream_t st) {
+    if (a.n_rays <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_composite, dim3((a.n_rays + 3) / 4), dim3(256), composite_lds_bytes(a.n), st, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_box_downsample(const float *rays, float *out, int w, int h, int s, hipStream_t st) {
+    const int total = w * h * 3;
+    if (total <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_box_downsample, dim3((total + 255) / 256), dim3(256), 0, st, rays, out, w, h, s);
+    return hipGetLastError();
+}

@@ -1,0 +1,292 @@
+"""GPU parity tests (-m gpu): the HIP path, called through the C ABI, against (1) the reference's golden scalars,
+(2) the committed oracle fixtures, (3) the oracle run live at small sizes, and (4) size-independent properties at
+BASELINE.json's full 800x800 size.  /root/reference is never read here.
+
+Stated tolerances (fp32):
+  forward_batch   |dsigma| <= 1e-4 (1 + |sigma|),  |drgb| <= 2e-5
+  ray dirs, stratified t       bit-exact (IEEE ops in the same order on both sides)
+  weights / cdf (same inputs)  <= 2e-6 abs (expf ulp differences only)
+  rendered pixels, same seed   max |d| <= 5e-4, mean |d| <= 1e-5, PSNR >= 90 dB      ("Gate 1")
+"""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import SCENE, golden, psnr
+
+pytestmark = pytest.mark.gpu
+
+SIGMA_TOL, RGB_TOL = 1e-4, 2e-5
+
+
+def _close_mlp(rgb, sig, ergb, esig):
+    ds = np.abs(sig - esig) / (1 + np.abs(esig))
+    dr = np.abs(rgb - ergb)
+    assert ds.max() <= SIGMA_TOL, f"sigma rel err {ds.max()}"
+    assert dr.max() <= RGB_TOL, f"rgb abs err {dr.max()}"
+
+
+def test_device_is_mi355x(renderer):
+    info = renderer.device_info()
+    assert info["arch"].startswith("gfx950") and info["n_cus"] >= 200
+
+
+# ---- S2: forward_batch ------------------------------------------------------------------------------------------
+def test_forward_batch_golden_scalars(renderer, samples):
+    """The reference's own unit test (src/lib.rs:753-916) through the HIP path, at the tight tolerance."""
+    origin = np.float32(samples["camera_origin"]); z = np.float32(samples["z_vals"])
+    n = 0
+    for ex in samples["examples"]:
+        rd = np.float32(ex["ray_d"])
+        pts = (origin[:, None] + rd[:, None] * z[None, :]).astype(np.float32)
+        dirs = np.tile(np.float32(ex["viewdir_unit"]), (5, 1))
+        for net, ks, kr in ((renderer.coarse, "coarse_sigma", "coarse_rgb"), (renderer.fine, "fine_sigma", "fine_rgb")):
+            rgb, sg = net.forward_batch(pts, dirs)
+            _close_mlp(rgb, sg, np.float32(ex[kr]), np.float32(ex[ks]))
+            n += sg.size + rgb.size
+    assert n == 120
+
+
+def test_forward_batch_fixture_4096(renderer):
+    g = golden("forward_batch_4096.npz")
+    for name, net in (("coarse", renderer.coarse), ("fine", renderer.fine)):
+        rgb, sg = net.forward_batch(g["pts"], g["dirs"])
+        _close_mlp(rgb, sg, g[f"{name}_rgb"], g[f"{name}_sigma"])
+
+
+@pytest.mark.parametrize("n", [0, 1, 31, 32, 33, 127, 128, 129, 1000])
+def test_forward_batch_ragged_sizes(renderer, n):
+    """Empty, single, and non-multiple-of-tile batches (tile = 128 points, wave = 32)."""
+    g = golden("forward_batch_4096.npz")
+    rgb, sg = renderer.fine.forward_batch(g["pts"][:, 100:100 + n], g["dirs"][100:100 + n])
+    assert rgb.shape == (n, 3) and sg.shape == (n,)
+    if n:
+        _close_mlp(rgb, sg, g["fine_rgb"][100:100 + n], g["fine_sigma"][100:100 + n])
+
+
+def test_forward_batch_vs_live_oracle_65536(renderer, oracle_nets):
+    """>= 64k random scene points, both networks, against the oracle run here."""
+    rng = np.random.default_rng(42)
+    n = 65536
+    pts = rng.uniform(-2.2, 2.2, size=(3, n)).astype(np.float32)
+    v = rng.normal(size=(n, 3)); dirs = (v / np.linalg.norm(v, axis=1, keepdims=True)).astype(np.float32)
+    for net, onet in ((renderer.coarse, oracle_nets[0]), (renderer.fine, oracle_nets[1])):
+        rgb, sg = net.forward_batch(pts, dirs)
+        ergb, esg = onet.forward_batch(pts, dirs)
+        _close_mlp(rgb, sg, ergb, esg)
+        assert np.isfinite(rgb).all() and np.isfinite(sg).all() and (sg >= 0).all()
+
+
+def test_forward_batch_is_deterministic_and_column_independent(renderer):
+    g = golden("forward_batch_4096.npz")
+    a = renderer.fine.forward_batch(g["pts"], g["dirs"])
+    b = renderer.fine.forward_batch(g["pts"], g["dirs"])
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    perm = np.random.default_rng(0).permutation(4096)
+    c = renderer.fine.forward_batch(g["pts"][:, perm], g["dirs"][perm])
+    assert np.array_equal(c[0], a[0][perm]) and np.array_equal(c[1], a[1][perm])  # each column is computed alone
+
+
+def test_forward_batch_argument_errors(renderer, native):
+    with pytest.raises(native.NerfError):
+        renderer.fine.forward_batch(np.zeros((2, 4), np.float32), np.zeros((4, 3), np.float32))
+    with pytest.raises(native.NerfError):
+        renderer.fine.forward_batch(np.zeros((3, 4), np.float32), np.zeros((5, 3), np.float32))
+
+
+# ---- a1-a3: rays and coarse samples are bit-exact ---------------------------------------------------------------------
+def test_ray_dirs_bit_exact(renderer, native, oracle, samples):
+    g = golden("ray_dirs.npz")
+    for n in (400, 800):
+        cam = native.camera_from_samples(samples, n, n)
+        full = renderer.stage_ray_dirs(cam, 0, 0, n, n, normalize=True)
+        raw = renderer.stage_ray_dirs(cam, 0, 0, n, n, normalize=False)
+        for k, (i, j) in enumerate(g[f"pix{n}"]):
+            assert np.array_equal(full[i, j], g[f"dirhat{n}"][k]) and np.array_equal(raw[i, j], g[f"dir{n}"][k])
+    ocam = oracle.camera_from_samples(samples, 800, 800)
+    win = renderer.stage_ray_dirs(cam, 700, 3, 9, 5)
+    for i in range(5):
+        for j in range(9):
+            assert np.array_equal(win[i, j], oracle.normalize(oracle.get_ray_dir(ocam, 3 + i, 700 + j)))
+
+
+def test_stratified_bit_exact(renderer, native, oracle, samples):
+    cam = native.camera_from_samples(samples, 800, 800)
+    g = golden("ray_stages_800.npz")
+    for r, (i, j) in enumerate(g["pixels"][:12]):
+        t = renderer.stage_stratified(cam, int(j), int(i), 1, 1, 64, seed=0)[0, 0]
+        assert np.array_equal(t, g["t_coarse"][r])
+    for count, seed in ((64, 1), (32, 7), (5, 3), (1, 0)):
+        t = renderer.stage_stratified(cam, 100, 200, 7, 3, count, seed=seed)
+        for i in range(3):
+            for j in range(7):
+                assert np.array_equal(t[i, j], oracle.stratified_samples(seed, (200 + i) * 800 + 100 + j, 2.0, 6.0, count))
+
+
+# ---- a9-a12 on identical inputs -----------------------------------------------------------------------------------
+def test_resample_stage_vs_fixtures(renderer):
+    g = golden("ray_stages_800.npz")
+    far = float(g["far"])
+    out = renderer.stage_resample(g["t_coarse"], g["sigma_coarse"], 128, far, seed=0, pixel_index=g["pixel_index"])
+    assert np.abs(out["w"] - g["w_coarse"]).max() <= 2e-6
+    assert np.abs(out["cdf"] - g["cdf"]).max() <= 2e-6
+    # t through the CDF: compare where the pdf is not flat (flat bins make t ill-conditioned)
+    pdf = np.diff(g["cdf"], axis=1)
+    idx = np.clip((g["cdf"][:, None, :] <= g["u_fine"][:, :, None]).sum(-1) - 1, 0, 61)
+    well = np.take_along_axis(pdf, idx, axis=1) > 1e-3
+    assert well.mean() > 0.5
+    assert np.abs(out["t_new"] - g["t_new"])[well].max() <= 2e-4
+    assert np.all(np.diff(out["t_fine"], axis=1) >= 0)
+    assert np.array_equal(np.sort(np.concatenate([g["t_coarse"], out["t_new"]], axis=1), axis=1), out["t_fine"])
+    # with the uniforms handed over explicitly the result is the same as with the in-kernel Philox stream
+    out_u = renderer.stage_resample(g["t_coarse"], g["sigma_coarse"], 128, far, u=g["u_fine"])
+    assert np.array_equal(out_u["t_fine"], out["t_fine"])
+
+
+def test_resample_exact_when_weights_are_exact(renderer, oracle):
+    """sigma == 0 -> weights are exactly 0 on both sides -> cdf, draws and merged t must be BIT-exact."""
+    g = golden("ray_stages_800.npz")
+    tc = g["t_coarse"][:6]; z = np.zeros_like(tc)
+    out = renderer.stage_resample(tc, z, 128, 6.0, seed=5, pixel_index=g["pixel_index"][:6])
+    for r in range(6):
+        w = oracle.compute_weights(z[r], tc[r], 6.0)
+        tn = oracle.sample_importance(5, int(g["pixel_index"][r]), tc[r], w, 128)
+        assert np.array_equal(out["t_new"][r], tn)
+        assert np.array_equal(out["t_fine"][r], oracle.sort_ascending(np.concatenate([tc[r], tn])))
+
+
+def test_integrate_stage_vs_fixtures(renderer, oracle):
+    g = golden("ray_stages_800.npz")
+    far = float(g["far"])
+    rgb, w = renderer.stage_integrate(g["rgb_fine"], g["sigma_fine"], g["t_merged"], far)
+    assert np.abs(w - g["w_fine"]).max() <= 2e-6 and np.abs(rgb - g["rgb"]).max() <= 5e-6
+    assert np.all(rgb[g["is_empty"]] == 1.0)                       # all-empty ray -> pure white
+    cut = g["is_terminated"]
+    assert np.array_equal(w[cut] == 0, g["w_fine"][cut] == 0)      # identical T < 1e-4 cut positions
+    # synthetic termination + ragged sample counts
+    for n in (1, 3, 64, 65, 192, 300):
+        rng = np.random.default_rng(n)
+        t = np.sort(rng.uniform(2, 6, size=(5, n)).astype(np.float32), axis=1)
+        s = rng.uniform(0, 40, size=(5, n)).astype(np.float32) * (rng.uniform(size=(5, n)) > 0.5)
+        c = rng.uniform(size=(5, n, 3)).astype(np.float32)
+        got, _ = renderer.stage_integrate(c, s, t, 6.0)
+        exp = np.stack([oracle.integrate_ray(c[r], s[r], t[r], 6.0) for r in range(5)])
+        assert np.abs(got - exp).max() <= 5e-6
+
+
+# ---- S3: render_image ---------------------------------------------------------------------------------------------
+def _gate1(img, ref):
+    d = np.abs(img - ref)
+    assert d.max() <= 5e-4 and d.mean() <= 1e-5 and psnr(img, ref) >= 90.0, (d.max(), d.mean(), psnr(img, ref))
+
+
+def test_render_c1_coarse_only_crop(renderer, native, samples):
+    """BASELINE config C1: 400x400 frame, 100x100 crop, coarse net only, 64 samples."""
+    g = golden("crop_c1_400_coarse_only.npz")
+    cam = native.camera_from_samples(samples, 400, 400, 64)
+    img = native.render_image(renderer.coarse, renderer.fine, cam, 0, seed=0, coarse_only=True, crop=tuple(int(v) for v in g["crop"]))
+    _gate1(img, g["image"])
+
+
+def test_render_c3_hierarchical_crop(renderer, native, samples):
+    """BASELINE config C3 geometry (800x800, 64 + 128): 64x64 crop vs the committed oracle image, seeds 0 and 1."""
+    cam = native.camera_from_samples(samples, 800, 800, 64)
+    for name, seed in (("crop_c3_800_64_128.npz", 0), ("crop_c3_800_64_128_seed1.npz", 1)):
+        g = golden(name)
+        img = native.render_image(renderer.coarse, renderer.fine, cam, 128, seed=seed, crop=tuple(int(v) for v in g["crop"]))
+        _gate1(img, g["image"])
+    # Gate 2 (north-star wording): against CPU image A (seed 0), GPU seed 1 and CPU seed 1 agree within 0.1 dB
+    a = golden("crop_c3_800_64_128.npz")["image"]; b = golden("crop_c3_800_64_128_seed1.npz")["image"]
+    assert abs(psnr(img, a) - psnr(b, a)) <= 0.1 and 30 < psnr(b, a) < 50
+
+
+def test_render_vs_live_oracle_ragged_window(renderer, native, oracle, oracle_nets, samples):
+    """A 21x13 window (not a multiple of the reference's 8x8 block) at the reference CLI's own 256x256 size."""
+    cam = native.camera_from_samples(samples, 256, 256, 64)
+    ocam = oracle.camera_from_samples(samples, 256, 256)
+    crop = (118, 101, 21, 13)
+    img = native.render_image(renderer.coarse, renderer.fine, cam, 128, seed=3, crop=crop)
+    ref = oracle.render_image(*oracle_nets, ocam, oracle.make_opts(64, 128, crop=crop, seed=3))
+    _gate1(img, ref)
+    # n_fine = 0: the fine network runs on the coarse samples only (src/lib.rs:295-297)
+    img0 = native.render_image(renderer.coarse, renderer.fine, cam, 0, seed=3, crop=(120, 104, 8, 8))
+    ref0 = oracle.render_image(*oracle_nets, ocam, oracle.make_opts(64, 0, crop=(120, 104, 8, 8), seed=3))
+    _gate1(img0, ref0)
+    # the wasm build's sample counts (32, 64) (src/lib.rs:604-607)
+    cam32 = native.camera_from_samples(samples, 256, 256, 32)
+    img32 = native.render_image(renderer.coarse, renderer.fine, cam32, 64, seed=3, crop=(120, 104, 8, 8))
+    ref32 = oracle.render_image(*oracle_nets, ocam, oracle.make_opts(32, 64, crop=(120, 104, 8, 8), seed=3))
+    _gate1(img32, ref32)
+
+
+def test_render_ssaa(renderer, native, samples):
+    g = golden("crop_ssaa2_400.npz")
+    cam = native.camera_from_samples(samples, 400, 400, 64)
+    img = native.render_image(renderer.coarse, renderer.fine, cam, 128, seed=0, crop=tuple(int(v) for v in g["crop"]), ssaa=2)
+    _gate1(img, g["image"])
+
+
+def test_render_argument_errors(renderer, native, samples):
+    cam = native.camera_from_samples(samples, 64, 64, 0)
+    with pytest.raises(native.NerfError) as e:
+        native.render_image(renderer.coarse, renderer.fine, cam, 128)
+    assert "coarse samples per ray must be greater than 0" in str(e.value)  # src/lib.rs:483-486
+    cam = native.camera_from_samples(samples, 64, 64, 64)
+    with pytest.raises(native.NerfError):
+        native.render_image(renderer.coarse, renderer.fine, cam, 128, crop=(60, 0, 8, 8))
+    with native.Renderer(0) as r2:
+        with pytest.raises(native.NerfError) as e:
+            native.render_image(native.Network(r2, 0), native.Network(r2, 1), cam, 128)
+        assert "not loaded" in str(e.value)
+
+
+# ---- full-size properties at BASELINE's 800x800, 64 + 128 ----------------------------------------------------------------
+@pytest.fixture(scope="module")
+def frame800(renderer, native, samples):
+    cam = native.camera_from_samples(samples, 800, 800, 64)
+    img, st = native.render_image(renderer.coarse, renderer.fine, cam, 128, seed=0, return_stats=True)
+    return cam, img, st
+
+
+def test_full_frame_contains_the_golden_crop(frame800):
+    cam, img, st = frame800
+    g = golden("crop_c3_800_64_128.npz")
+    x0, y0, w, h = (int(v) for v in g["crop"])
+    _gate1(img[y0:y0 + h, x0:x0 + w], g["image"])
+    assert st.n_rays == 640000 and st.n_coarse_points == 640000 * 64 and st.n_fine_points == 640000 * 192
+    assert img.shape == (800, 800, 3) and np.isfinite(img).all()
+    assert img.min() >= -1e-5 and img.max() <= 1 + 1e-5
+
+
+def test_full_frame_is_deterministic_and_band_invariant(renderer, native, frame800):
+    """Same seed -> identical bits; rendering in row bands / small passes (the multi-GPU decomposition) or as a crop
+    gives the same bits as the single full-frame pass: per-pixel RNG, no cross-ray state."""
+    cam, img, _ = frame800
+    band = native.render_image(renderer.coarse, renderer.fine, cam, 128, seed=0, crop=(0, 300, 800, 100))  # GPU 3 of 8
+    assert np.array_equal(band, img[300:400])
+    crop = native.render_image(renderer.coarse, renderer.fine, cam, 128, seed=0, crop=(123, 457, 77, 19))
+    assert np.array_equal(crop, img[457:476, 123:200])
+    again = native.render_image(renderer.coarse, renderer.fine, cam, 128, seed=0, crop=(0, 300, 800, 100))
+    assert np.array_equal(again, band)
+
+
+def test_full_frame_scene_statistics(frame800, native, renderer):
+    """Scene-level invariants: most of the lego frame is pure white background (~75 %), borders are
+    white, a different seed changes only the jitter noise (~40 dB)."""
+    cam, img, _ = frame800
+    white = np.all(img == 1.0, axis=2)
+    assert 0.60 < white.mean() < 0.90
+    assert white[:40].all() and white[-40:].all() and white[:, :40].all() and white[:, -40:].all()
+    other = native.render_image(renderer.coarse, renderer.fine, cam, 128, seed=1, crop=(200, 200, 400, 400))
+    p = psnr(other, img[200:600, 200:600])
+    assert 30.0 < p < 50.0 and not np.array_equal(other, img[200:600, 200:600])
+
+
+def test_ppm_of_full_frame(frame800, native, oracle, tmp_path):
+    cam, img, _ = frame800
+    p = tmp_path / "output.ppm"
+    native.save_ppm(p, 800, 800, img)
+    raw = p.read_bytes()
+    assert raw[:15] == b"P6\n800 800\n255\n" and len(raw) == 15 + 800 * 800 * 3
+    assert np.array_equal(np.frombuffer(raw[15:], np.uint8), oracle.quantize_rgb8(img).reshape(-1))

@@ -1,0 +1,242 @@
+"""CPU tests of the product's host side through the C ABI: exported symbols vs the header, loader failure cases,
+camera-from-JSON, PPM writer, and the packed weight layout (emulated lane-by-lane in numpy against the oracle).
+No device call is made here (no GPU in the build container)."""
+import ctypes as C
+import os
+import re
+import shutil
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, SCENE
+
+HEADER = os.path.join(ROOT, "include", "nerf_mi355x.h")
+
+
+def test_abi_exports_every_declared_symbol(native):
+    """Every function include/nerf_mi355x.h declares is exported by the .so and has a ctypes prototype."""
+    from nerf_rs_amd import _lib
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    declared = set(re.findall(r"\b(nerf_[a-z0-9_]+)\s*\(", text))
+    declared -= {"nerf_ctx"}
+    assert len(declared) >= 20
+    L = C.CDLL(native.lib_path())
+    for name in declared:
+        assert hasattr(L, name), f"{name} declared in the header but not exported"
+        assert name in _lib.PROTOTYPES, f"{name} has no ctypes prototype"
+    assert set(_lib.PROTOTYPES) == declared
+    assert native.load_library().nerf_abi_version() == 1
+
+
+def test_no_device_means_loud_failure(native):
+    """Without a HIP device nerf_create must fail (no CPU fallback).  Skipped where a GPU exists."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(native.NerfError) as e:
+        native.Renderer(0)
+    assert "no CPU fallback" in str(e.value) or "HIP" in str(e.value)
+
+
+def test_product_never_touches_the_oracle():
+    """The oracle is test infrastructure: nothing under nerf-rs_amd/ may reference it."""
+    pkg = os.path.join(ROOT, "nerf-rs_amd")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h", "Makefile")):
+                src = open(os.path.join(dp, f), errors="ignore").read()
+                assert "oracle_py" not in src and "nerf_oracle" not in src and "libnerf_oracle" not in src, (dp, f)
+
+
+def _check(native, d):
+    return native.load_library().nerf_check_network_dir(str(d).encode()), \
+        (native.load_library().nerf_last_error(None) or b"").decode()
+
+
+def test_loader_failure_cases(native, tmp_path):
+    """load_network_from_dir's failure cases (src/lib.rs:36, 65, 118, 127) as status codes + messages."""
+    assert _check(native, os.path.join(SCENE, "coarse"))[0] == 0
+    assert _check(native, os.path.join(SCENE, "fine"))[0] == 0
+    rc, msg = _check(native, tmp_path / "nope")
+    assert rc == -2 and "read shapes" in msg
+    d = tmp_path / "net"; shutil.copytree(os.path.join(SCENE, "coarse"), d)
+    os.remove(d / "dense3_kernel.bin")
+    rc, msg = _check(native, d)
+    assert rc == -2 and "read tensor" in msg and "dense3_kernel" in msg
+    shutil.copy(os.path.join(SCENE, "coarse", "dense3_kernel.bin"), d / "dense3_kernel.bin")
+    lines = [l for l in open(d / "shapes.txt") if not l.startswith("alpha_bias")]
+    open(d / "shapes.txt", "w").writelines(lines)
+    rc, msg = _check(native, d)
+    assert rc == -3 and msg == "missing bias parameter: alpha_bias"
+    lines = [l for l in lines if not l.startswith("rgb_kernel")]
+    open(d / "shapes.txt", "w").writelines(lines)
+    rc, msg = _check(native, d)
+    assert rc == -3 and msg == "missing matrix parameter: rgb_kernel"
+    shutil.copy(os.path.join(SCENE, "coarse", "shapes.txt"), d / "shapes.txt")
+    with open(d / "dense0_kernel.bin", "ab") as f:
+        f.write(b"\0" * 8)
+    rc, msg = _check(native, d)
+    assert rc == -4 and "dims mismatch for dense0_kernel" in msg
+    # an unused extra tensor is tolerated (only a debug_assert in the reference, src/lib.rs:171)
+    shutil.copy(os.path.join(SCENE, "coarse", "dense0_kernel.bin"), d / "dense0_kernel.bin")
+    np.zeros(4, np.float32).tofile(d / "extra.bin")
+    with open(d / "shapes.txt", "a") as f:
+        f.write("extra 4\n")
+    assert _check(native, d)[0] == 0
+
+
+def test_camera_from_json_matches_oracle_bitwise(native, oracle, samples):
+    for w, h in ((256, 256), (400, 400), (800, 600)):
+        a = native.camera_from_samples(os.path.join(SCENE, "tf_reference_samples.json"), w, h).c
+        b = native.camera_from_samples(samples, w, h).c
+        o = oracle.camera_from_samples(samples, w, h)
+        for cam in (a, b):
+            assert (cam.nx, cam.ny) == (o.nx, o.ny) == (w, h)
+            for f in ("alpha_width", "alpha_height", "near", "far"):
+                assert np.float32(getattr(cam, f)).tobytes() == np.float32(getattr(o, f)).tobytes()
+            for f in ("pos", "dir", "up"):
+                assert list(getattr(cam, f)) == list(getattr(o, f))
+    assert abs(np.tan(a.alpha_width) - 0.36) < 1e-6 and (a.near, a.far) == (2.0, 6.0)
+
+
+def test_camera_json_errors(native, tmp_path):
+    L = native.load_library()
+    from nerf_rs_amd._lib import CCamera
+    cam = CCamera()
+    assert L.nerf_camera_from_json(str(tmp_path / "missing.json").encode(), 8, 8, C.byref(cam)) == -2
+    p = tmp_path / "bad.json"; p.write_text('{"near": 2.0, "far": 6.0, "hwf": [400, 400')
+    assert L.nerf_camera_from_json(str(p).encode(), 8, 8, C.byref(cam)) == -7
+    p.write_text('{"near": 2.0, "far": 6.0, "hwf": [400, 400, 555.5], "camera_origin": [0,0,0], "camera_up": [0,0,1]}')
+    assert L.nerf_camera_from_json(str(p).encode(), 8, 8, C.byref(cam)) == -7
+    assert b"camera_forward" in L.nerf_last_error(None)
+    with pytest.raises(native.NerfError):
+        native.camera_from_samples({"near": 2.0}, 8, 8)
+
+
+def test_save_ppm_matches_oracle(native, oracle, tmp_path):
+    rng = np.random.default_rng(3)
+    img = rng.uniform(-0.2, 1.2, size=(5, 7, 3)).astype(np.float32)
+    img[0, 0] = [np.nan, 0.5, 1.0]
+    assert np.array_equal(native.quantize_rgb8(img), oracle.quantize_rgb8(img))
+    a, b = tmp_path / "a.ppm", tmp_path / "b.ppm"
+    native.save_ppm(a, 7, 5, img); oracle.save_ppm(b, img)
+    assert a.read_bytes() == b.read_bytes() and a.read_bytes().startswith(b"P6\n7 5\n255\n")
+    with pytest.raises(native.NerfError):
+        native.save_ppm(a, 6, 5, img)  # assert_eq!(pixels.len(), width * height), src/lib.rs:569
+
+
+# ---- packed weight layout: numpy emulation of the kernel's lane/register layout (mlp_layout.h) --------------------
+def _pack(native, which):
+    L = native.load_library()
+    nw, ns = C.c_size_t(), C.c_size_t()
+    d = os.path.join(SCENE, which).encode()
+    assert L.nerf_debug_pack_network_dir(d, None, 0, None, 0, C.byref(nw), C.byref(ns)) == 0
+    ws = np.empty(nw.value, np.float32); sm = np.empty(ns.value, np.float32)
+    f32p = C.POINTER(C.c_float)
+    assert L.nerf_debug_pack_network_dir(d, ws.ctypes.data_as(f32p), ws.size, sm.ctypes.data_as(f32p), sm.size, None, None) == 0
+    return ws, sm
+
+
+LANE = np.arange(64); P_ = LANE & 31; H_ = LANE >> 5
+ROW_OF = np.array([[(r & 3) + 8 * (r >> 2) + 4 * h for h in (0, 1)] for r in range(16)])  # [r][h]
+
+
+def _mfma(acc, a, b):
+    """v_mfma_f32_32x32x2_f32: A[i=l&31][k=l>>5] = a[l], B[k=l>>5][j=l&31] = b[l]; D reg r of lane l =
+    D[(r&3)+8(r>>2)+4(l>>5)][l&31]."""
+    D = a.reshape(2, 32).T.astype(np.float64) @ b.reshape(2, 32).astype(np.float64)
+    acc += D[ROW_OF[:, H_], P_[None, :]]
+
+
+def _emulate_wave(ws, sm, pts, dirs):
+    """One 32-point wave tile through the full network exactly as mlp_kernel.hip walks the stream."""
+    BIAS, BIASV, AW, RW, MISC = 0, 9 * 256, 9 * 256 + 128, 9 * 256 + 128 + 256, 9 * 256 + 128 + 256 + 384
+    pos = pts[:, P_]; d = dirs[P_].T
+    E = np.zeros((2, 16, 64))
+    f0 = np.where(H_ == 1, 32.0, 1.0)
+    for o in range(5):
+        for ax in range(3):
+            arg = np.float32(f0 * 2.0 ** o) * pos[ax]
+            for idx, val in ((6 * o + ax, np.sin(np.float64(arg))), (6 * o + 3 + ax, np.cos(np.float64(arg)))):
+                E[idx >> 4, idx & 15] = val
+    E[1, 14] = np.where(H_ == 1, pos[2], pos[0]); E[1, 15] = np.where(H_ == 1, 0.0, pos[1])
+    cur = [0]
+
+    def bias(off, nt):
+        return np.stack([sm[off + (t * 2 + H_) * 16 + r] for t in range(nt) for r in range(16)]).reshape(nt, 16, 64).astype(np.float64)
+
+    def steps(inp, out, relu):  # one input tile (16 k-steps)
+        nt = out.shape[0]
+        for r in range(16):
+            b = np.maximum(inp[r], 0) if relu else inp[r]
+            for g in range(nt // 4):
+                piece = ws[cur[0]: cur[0] + 256].reshape(64, 4); cur[0] += 256
+                for q in range(4):
+                    _mfma(out[4 * g + q], piece[:, q], b)
+
+    X = bias(BIAS, 8); steps(E[0], X, False); steps(E[1], X, False)
+    for layer in range(1, 5):
+        Y = bias(BIAS + layer * 256, 8)
+        for t in range(8):
+            steps(X[t], Y, True)
+        X = Y
+    Y = bias(BIAS + 5 * 256, 8); steps(E[0], Y, False); steps(E[1], Y, False)
+    for t in range(8):
+        steps(X[t], Y, True)
+    X = Y
+    for layer in (6, 7):
+        Y = bias(BIAS + layer * 256, 8)
+        for t in range(8):
+            steps(X[t], Y, True)
+        X = Y
+    assert cur[0] == 120 * 4096
+    aw = np.stack([sm[AW + H_ * 128 + k] for k in range(128)]).reshape(8, 16, 64)
+    part = (aw * np.maximum(X, 0)).sum(axis=(0, 1))
+    sigma = np.maximum(part + part[LANE ^ 32] + sm[MISC], 0)
+    B = bias(BIAS + 8 * 256, 8)
+    for t in range(8):
+        steps(X[t], B, True)
+    D = np.zeros((16, 64))
+    f = np.where(H_ == 1, 4.0, 1.0)
+    for o in range(2):
+        for ax in range(3):
+            arg = np.float32(f * 2.0 ** o) * d[ax]
+            D[6 * o + ax] = np.sin(np.float64(arg)); D[6 * o + 3 + ax] = np.cos(np.float64(arg))
+    for ax in range(3):
+        D[12 + ax] = np.where(H_ == 1, 0.0, d[ax])
+    V = bias(BIASV, 4)
+    for t in range(8):
+        steps(B[t], V, False)
+    steps(D, V, False)
+    assert cur[0] == 145 * 4096 == ws.size
+    rgb = np.zeros((3, 64))
+    for c in range(3):
+        rw = np.stack([sm[RW + (H_ * 3 + c) * 64 + k] for k in range(64)]).reshape(4, 16, 64)
+        part = (rw * np.maximum(V, 0)).sum(axis=(0, 1))
+        rgb[c] = 1.0 / (1.0 + np.exp(-(part + part[LANE ^ 32] + sm[MISC + 1 + c])))
+    return rgb[:, :32].T, sigma[:32]
+
+
+@pytest.mark.parametrize("which", ["coarse", "fine"])
+def test_packed_layout_reproduces_the_network(native, oracle, samples, oracle_nets, which):
+    ws, sm = _pack(native, which)
+    assert ws.size == 145 * 4096 and sm.size % 64 == 0
+    origin = np.float32(samples["camera_origin"]); z = np.float32(samples["z_vals"])
+    pts = np.zeros((3, 32), np.float32); dirs = np.zeros((32, 3), np.float32); dirs[:, 2] = 1
+    exp_s, exp_c = [], []
+    for e, ex in enumerate(samples["examples"]):
+        rd = np.float32(ex["ray_d"])
+        pts[:, 5 * e: 5 * e + 5] = origin[:, None] + rd[:, None] * z[None, :]
+        dirs[5 * e: 5 * e + 5] = np.float32(ex["viewdir_unit"])
+        exp_s += ex[f"{which}_sigma"]; exp_c += ex[f"{which}_rgb"]
+    rng = np.random.default_rng(1)
+    pts[:, 15:] = rng.uniform(-2.2, 2.2, size=(3, 17)); v = rng.normal(size=(17, 3))
+    dirs[15:] = v / np.linalg.norm(v, axis=1, keepdims=True)
+    rgb, sigma = _emulate_wave(ws, sm, pts, dirs)
+    exp_s, exp_c = np.float32(exp_s), np.float32(exp_c)
+    assert np.all(np.abs(sigma[:15] - exp_s) <= 1e-4 * (1 + np.abs(exp_s)))      # the reference's golden scalars
+    assert np.all(np.abs(rgb[:15] - exp_c) <= 1e-5)
+    o_rgb, o_sig = oracle_nets[0 if which == "coarse" else 1].forward_batch(pts, dirs)
+    assert np.all(np.abs(sigma - o_sig) <= 1e-4 * (1 + np.abs(o_sig))) and np.all(np.abs(rgb - o_rgb) <= 1e-5)
