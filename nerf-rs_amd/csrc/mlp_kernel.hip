@@ -103,10 +103,12 @@ __device__ __forceinline__ void pipe_advance(Pipe &P, f32x4 &a0, f32x4 &a1) {
     __builtin_amdgcn_sched_barrier(0);
 }
 
+// ReLU as a signed-integer max on the bit pattern: one v_max_i32 (fmaxf costs an extra canonicalising v_max), and --
+// unlike inline asm -- visible to hipcc's hazard recogniser, which must pad the VALU-write -> MFMA-operand-read
+// wait states.  Negative floats and -0.0 are negative integers -> +0.0; positives are unchanged.
 __device__ __forceinline__ float relu(float v) {
-    float r;
-    asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(v));
-    return r;
+    const int b = __builtin_bit_cast(int, v);
+    return __builtin_bit_cast(float, b > 0 ? b : 0);
 }
 
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
