@@ -21,7 +21,20 @@ sys.path.insert(0, ROOT)
 PEAK_FP32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 
 
-def cpu_baseline(width, height, n_coarse, n_fine, seed):
+def host_cores():
+    """Threads to use on the host: the affinity mask, capped by the cgroup CPU quota (the GPU box gives a share of a
+    large host; oversubscribing it would measure the scheduler, not the code) and by 32."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, 32))
+
+
+def cpu_baseline(width, height, n_coarse, n_fine, seed, block_rows=2):
     """Oracle (kind: "port") on the host cores: one 8x8 block per thread, forward_fallback's loop order."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle_py as O
@@ -29,13 +42,14 @@ def cpu_baseline(width, height, n_coarse, n_fine, seed):
     S = O.load_samples(os.path.join(scene, "tf_reference_samples.json"))
     co, fi = O.Net(os.path.join(scene, "coarse")), O.Net(os.path.join(scene, "fine"))
     cam = O.camera_from_samples(S, width, height)
-    cores = len(os.sched_getaffinity(0))
-    # one 8x8 block (the reference's rayon task, src/lib.rs:491,533) per thread, centred on the model
-    bw = 1
-    while bw * bw < cores:
-        bw += 1
-    bh = (cores + bw - 1) // bw
-    crop = (width // 2 - 4 * bw, height // 2 - 4 * bh, 8 * bw, 8 * bh)
+    cores = host_cores()
+    # One task per thread, centred on the model.  The reference's rayon task is an 8x8 block (src/lib.rs:491,533), but
+    # in the reference's loop order one such block takes ~110 s on this class of host (measured: 9.07 rays/s on 16
+    # threads, 16 blocks, round-1 run), so the default sample uses 8x2-ray strips (16 rays, B = 1024 / 3072 columns
+    # per forward_batch) to stay near 30 s; --cpu-block-rows 8 times the full 8x8 blocks.
+    bh = max(d for d in range(1, int(cores ** 0.5) + 1) if cores % d == 0)  # bw * bh == cores exactly
+    bw = cores // bh
+    crop = (width // 2 - 4 * bw, height // 2 - (block_rows * bh) // 2, 8 * bw, block_rows * bh)
     n_rays = crop[2] * crop[3]
     t0 = time.time()
     O.render_image(co, fi, cam, O.make_opts(n_coarse, n_fine, crop=crop, seed=seed, naive=True, threads=cores))
@@ -45,7 +59,7 @@ def cpu_baseline(width, height, n_coarse, n_fine, seed):
     dt_blocked = time.time() - t0
     return {"value": n_rays / dt, "unit": "rays/s", "cores": cores, "kind": "port",
             "sample": f"{crop[2]}x{crop[3]} crop at ({crop[0]},{crop[1]}) of the {width}x{height} frame = {n_rays} rays "
-                      f"({n_rays // 64} 8x8 blocks, one per thread), {n_coarse}+{n_fine} samples, reference loop order "
+                      f"({bw * bh} tasks of 8x{block_rows} rays, one per thread), {n_coarse}+{n_fine} samples, reference loop order "
                       f"(src/network.rs:134-143), {dt:.1f} s; baseline, not target",
             "cache_blocked_variant_rays_per_s": n_rays / dt_blocked}
 
@@ -61,6 +75,7 @@ def main():
     ap.add_argument("--fine", type=int, default=128)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-block-rows", type=int, default=2, help="rows of each 8-wide CPU task (8 = the reference's 8x8 block)")
     args = ap.parse_args()
 
     import torch
@@ -132,7 +147,7 @@ def main():
                          "points_per_launch": pts_dom // max(n_dom, 1), "flop_per_point": N.FLOP_PER_POINT_FULL},
         }
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(args.width, args.height, args.coarse, args.fine, args.seed)
+            line["cpu_baseline"] = cpu_baseline(args.width, args.height, args.coarse, args.fine, args.seed, args.cpu_block_rows)
         print(json.dumps(line), flush=True)
     del out
     r.close()

@@ -118,6 +118,10 @@ int nerf_render_image_device(nerf_ctx *ctx, const nerf_camera *cam, const nerf_r
 int nerf_kernel_time_query(nerf_ctx *ctx, double *ms_dominant_mlp, uint64_t *points_dominant_mlp, uint32_t *n_launches,
                            int reset);
 
+/* Diagnostic: median in-kernel shader clock (MHz) of the last fine-network MLP launch, from s_memtime / s_memrealtime
+ * stamps around the tile loop.  Only available when NERF_DEBUG_CLOCK=1 was set before nerf_create. */
+int nerf_debug_shader_clock_mhz(nerf_ctx *ctx, double *mhz);
+
 /* ---- host helpers around the path ------------------------------------------------------------------------ */
 /* camera_from_samples (src/lib.rs:614-645): reads near, far, camera_origin, camera_forward, camera_up, hwf. */
 int nerf_camera_from_json(const char *json_path, int width, int height, nerf_camera *out);

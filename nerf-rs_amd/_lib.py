@@ -58,6 +58,7 @@ PROTOTYPES = {
                                            C.POINTER(CStats)]),
     "nerf_kernel_time_query": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64),
                                          C.POINTER(C.c_uint32), C.c_int]),
+    "nerf_debug_shader_clock_mhz": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
     "nerf_camera_from_json": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.POINTER(CCamera)]),
     "nerf_camera_from_values": (C.c_int, [C.c_float, C.c_float, f32p, f32p, f32p, f32p, C.c_int, C.c_int,
                                           C.POINTER(CCamera)]),
@@ -73,7 +74,8 @@ PROTOTYPES = {
 
 
 def lib_path():
-    return os.path.join(_HERE, "libnerf_mi355x.so")
+    """In-tree extension; NERF_MI355X_LIB selects another build of the same library (tuning variants)."""
+    return os.environ.get("NERF_MI355X_LIB") or os.path.join(_HERE, "libnerf_mi355x.so")
 
 
 def build_native(force=False):

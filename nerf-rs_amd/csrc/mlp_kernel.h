@@ -20,6 +20,7 @@ struct MlpArgs {
     // outputs
     float *sigma_out; // n
     float *rgb_out;   // n x 3 (full kernels only)
+    unsigned long long *clock_out; // optional diagnostic: per workgroup {shader cycles, 100 MHz ticks} of the tile loop
 };
 
 // Sets the dynamic-LDS attribute of every kernel instantiation on the current device.

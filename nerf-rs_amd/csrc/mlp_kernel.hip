@@ -23,6 +23,34 @@
 
 using namespace nerfmlp;
 
+// Tuning switches (A/B-tested on MI355X).
+#ifndef NERF_DMA_SPREAD
+#define NERF_DMA_SPREAD 1 // 1: one LDS-DMA piece per macro-step behind an MFMA; 0: four pieces in a burst at the sync
+#endif
+#ifndef NERF_FAST_SINCOS
+#define NERF_FAST_SINCOS 1 // 1: branch-free Cody-Waite + minimax sincos (<= 1.6 ulp for |x| <= 2^11); 0: ocml sincosf
+#endif
+// Timing-only diagnostics (results are WRONG with any of these set; never shipped):
+#ifndef NERF_DIAG_NO_BARRIER
+#define NERF_DIAG_NO_BARRIER 0
+#endif
+#ifndef NERF_DIAG_NO_DMA
+#define NERF_DIAG_NO_DMA 0
+#endif
+#ifndef NERF_DIAG_NO_LDS
+#define NERF_DIAG_NO_LDS 0
+#endif
+#define NERF_STR2(x) #x
+#define NERF_STR(x) NERF_STR2(x)
+// chunks allowed to stay in flight across the mid-chunk sync: kRingSlots - 3 (4 pieces each)
+#define NERF_SYNC_VMCNT ((NERF_RING_SLOTS - 3) * 4)
+#ifndef NERF_LOOP_LAYERS
+#define NERF_LOOP_LAYERS 0 // (measured slower: 87.1 % vs 87.8 %; kept for the record) 1: dense1..7 + bottleneck as a runtime loop over 4 layer pairs (instruction-cache resident)
+#endif
+#ifndef NERF_PREFETCH_INPUTS
+#define NERF_PREFETCH_INPUTS 1 // 1: the next tile's t / direction are loaded one tile ahead
+#endif
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -34,70 +62,111 @@ namespace {
 // The stream is consumed in "macro-steps" of 2 KiB = the A operands of 8 MFMAs (one k-step of an
 // 8-tile layer, or two k-steps of the 4-tile viewdirs layer); 8 macro-steps per 16-KiB chunk.
 struct Pipe {
-    const LDS_AS char *rd;   // LDS address (incl. lane*16) of the NEXT macro-step to fetch
-    const LDS_AS char *ring_lo, *ring_hi; // ring bounds (incl. lane*16)
+    const LDS_AS char *rd_base; // LDS address (incl. lane*16) of the chunk the NEXT macro-step to fetch lives in
+    const LDS_AS char *ring_lane; // ring base + lane*16
+    uint32_t rd_slot_off;       // wave-uniform byte offset of that chunk's slot
     f32x4 a0, a1;            // prefetched A operands of the current macro-step
     uint32_t ring_addr;      // LDS byte address of the ring + wave*4 KiB (DMA destination base)
     uint32_t wr_slot_off;    // byte offset of the slot the next DMA chunk goes to
     uint32_t next_off;       // byte offset in the stream of the next chunk to DMA
     uint32_t stream_bytes;   // bytes per tile
     const char *gbase;       // wave-uniform: stream + wave*4 KiB
+    const char *cur_src;     // wave-uniform: this wave's quarter of the chunk being DMA'd
+    uint32_t cur_dst;        // its LDS destination
     uint32_t lane16;
 };
 
-// Four 1-KiB LDS-DMA pieces (this wave's quarter of a chunk).  Hidden from the compiler's waitcnt
-// bookkeeping on purpose (it would drain vmcnt(0) in front of every later ds_read); completion is
-// enforced by the explicit vmcnt(0) + s_barrier in pipe_sync_prefetch().
-__device__ __forceinline__ void glds_chunk_quarter(uint32_t lane16, const char *gsrc, uint32_t d0) {
-    // No instruction offsets: the immediate of global_load_lds is applied to the global AND the LDS address, so
-    // every piece gets its own scalar base and its own M0 instead.
+// One 1-KiB LDS-DMA piece (64 lanes x 16 B, lane-linear in LDS).  Hidden from the compiler's waitcnt bookkeeping on
+// purpose (it would drain vmcnt(0) in front of every later ds_read); completion is enforced by the explicit
+// vmcnt(0) + s_barrier in pipe_sync().  No instruction offset: the immediate of global_load_lds applies to the global
+// AND the LDS address.
+__device__ __forceinline__ void glds_piece(uint32_t lane16, const char *gsrc, uint32_t dst) {
     uint32_t keep;
-    const char *g1 = gsrc + 1024, *g2 = gsrc + 2048, *g3 = gsrc + 3072;
-    const uint32_t d1 = d0 + 1024, d2 = d0 + 2048, d3 = d0 + 3072;
     asm volatile("s_mov_b32 %0, m0\n\t"
-                 "s_mov_b32 m0, %6\n\t"
+                 "s_mov_b32 m0, %3\n\t"
                  "s_nop 0\n\t"
                  "global_load_lds_dwordx4 %1, %2\n\t"
-                 "s_mov_b32 m0, %7\n\t"
-                 "s_nop 0\n\t"
-                 "global_load_lds_dwordx4 %1, %3\n\t"
-                 "s_mov_b32 m0, %8\n\t"
-                 "s_nop 0\n\t"
-                 "global_load_lds_dwordx4 %1, %4\n\t"
-                 "s_mov_b32 m0, %9\n\t"
-                 "s_nop 0\n\t"
-                 "global_load_lds_dwordx4 %1, %5\n\t"
                  "s_mov_b32 m0, %0"
                  : "=&s"(keep)
-                 : "v"(lane16), "s"(gsrc), "s"(g1), "s"(g2), "s"(g3), "s"(d0), "s"(d1), "s"(d2), "s"(d3)
+                 : "v"(lane16), "s"(gsrc), "s"(dst)
                  : "memory");
 }
 
-__device__ __forceinline__ void pipe_issue(Pipe &P) {
+// Select the next chunk: its stream offset and ring slot (kept opaque so the 145 values are not constant-folded
+// into 145 live address registers).
+__device__ __forceinline__ void pipe_next_chunk(Pipe &P) {
     uint32_t off = P.next_off, slot = P.wr_slot_off;
-    asm volatile("" : "+s"(off), "+s"(slot)); // keep the running offsets opaque (no 145-way constant folding)
-    glds_chunk_quarter(P.lane16, P.gbase + off, P.ring_addr + slot);
+    asm volatile("" : "+s"(off), "+s"(slot));
+    P.cur_src = P.gbase + off;
+    P.cur_dst = P.ring_addr + slot;
     off += kChunkBytes;
     P.next_off = (off == P.stream_bytes) ? 0u : off;
     slot += kChunkBytes;
     P.wr_slot_off = (slot == kRingSlots * kChunkBytes) ? 0u : slot;
 }
 
-// Middle of chunk c: chunk c+1 (issued one chunk ago) must have landed; every wave is past chunk c-1, so
-// its slot can be refilled with chunk c+2.
-__device__ __forceinline__ void pipe_sync_prefetch(Pipe &P) {
-    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-    pipe_issue(P);
+__device__ __forceinline__ void pipe_issue_piece(Pipe &P, int i) {
+#if !NERF_DIAG_NO_DMA
+    glds_piece(P.lane16, P.cur_src + i * 1024, P.cur_dst + i * 1024);
+#else
+    (void)P; (void)i;
+#endif
 }
 
-// Take the prefetched operands of the current macro-step and start fetching the next one.
-__device__ __forceinline__ void pipe_advance(Pipe &P, f32x4 &a0, f32x4 &a1) {
+__device__ __forceinline__ void pipe_issue(Pipe &P) {
+    pipe_next_chunk(P);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) pipe_issue_piece(P, i);
+}
+
+// Middle of chunk c: chunk c+1 (issued one chunk ago) must have landed; every wave is past chunk c-1, so
+// its slot can be refilled with chunk c+2 (macro-steps 4..7 of chunk c issue one piece each, or all four here).
+__device__ __forceinline__ void pipe_sync(Pipe &P) {
+#if NERF_DIAG_NO_BARRIER
+    asm volatile("s_waitcnt vmcnt(" NERF_STR(NERF_SYNC_VMCNT) ")" ::: "memory");
+#else
+    asm volatile("s_waitcnt vmcnt(" NERF_STR(NERF_SYNC_VMCNT) ")\n\ts_barrier" ::: "memory");
+#endif
+#if NERF_DMA_SPREAD
+    pipe_next_chunk(P);
+#else
+    pipe_issue(P);
+#endif
+}
+
+// Called between the MFMAs of macro-step `ms` (0..7 within its chunk).
+__device__ __forceinline__ void pipe_mid_step(Pipe &P, int ms) {
+#if NERF_DMA_SPREAD
+    if (ms >= 4) {
+        __builtin_amdgcn_sched_barrier(0);
+        pipe_issue_piece(P, ms - 4);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#else
+    (void)P; (void)ms;
+#endif
+}
+
+// Take the prefetched operands of macro-step `ms` (0..7 within its chunk) and start fetching those of the next one.
+// All in-chunk addressing is a per-chunk base + immediate offset: VALU instructions are NOT free next to fp32 MFMAs
+// (they share the vector datapath), so the ring arithmetic is one v_add per chunk plus scalar ops.
+__device__ __forceinline__ void pipe_advance(Pipe &P, int ms, f32x4 &a0, f32x4 &a1) {
     a0 = P.a0;
     a1 = P.a1;
-    P.a0 = *(const LDS_AS f32x4 *)(P.rd);
-    P.a1 = *(const LDS_AS f32x4 *)(P.rd + 1024);
-    const LDS_AS char *n = P.rd + 2048;
-    P.rd = (n == P.ring_hi) ? P.ring_lo : n;
+    int nxt = ms + 1;
+    if (nxt == 8) {
+        uint32_t off = P.rd_slot_off + kChunkBytes;
+        off = (off == kRingSlots * kChunkBytes) ? 0u : off;
+        P.rd_slot_off = off;
+        P.rd_base = P.ring_lane + off;
+        nxt = 0;
+    }
+#if NERF_DIAG_NO_LDS
+    asm volatile("" : "+v"(P.a0), "+v"(P.a1));
+#else
+    P.a0 = *(const LDS_AS f32x4 *)(P.rd_base + nxt * 2048);
+    P.a1 = *(const LDS_AS f32x4 *)(P.rd_base + nxt * 2048 + 1024);
+#endif
     // keep the two ds_reads of the NEXT macro-step ahead of this macro-step's MFMAs (otherwise hipcc sinks
     // them below the MFMAs into the same registers and exposes the LDS latency every 8 MFMAs)
     __builtin_amdgcn_sched_barrier(0);
@@ -123,10 +192,11 @@ __device__ __forceinline__ void tile_steps(const f32x16 &in, f32x16 (&out)[NT], 
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             f32x4 a0, a1;
-            if ((r & 7) == 4) pipe_sync_prefetch(P);
-            pipe_advance(P, a0, a1);
+            if ((r & 7) == 4) pipe_sync(P);
+            pipe_advance(P, r & 7, a0, a1);
             const float b = RELU ? relu(in[r]) : in[r];
             out[0] = MFMA(a0[0], b, out[0]); out[1] = MFMA(a0[1], b, out[1]);
+            pipe_mid_step(P, r & 7);
             out[2] = MFMA(a0[2], b, out[2]); out[3] = MFMA(a0[3], b, out[3]);
             out[4] = MFMA(a1[0], b, out[4]); out[5] = MFMA(a1[1], b, out[5]);
             out[6] = MFMA(a1[2], b, out[6]); out[7] = MFMA(a1[3], b, out[7]);
@@ -135,11 +205,12 @@ __device__ __forceinline__ void tile_steps(const f32x16 &in, f32x16 (&out)[NT], 
 #pragma unroll
         for (int r = 0; r < 16; r += 2) {
             f32x4 a0, a1;
-            if (r / 2 == 4) pipe_sync_prefetch(P);
-            pipe_advance(P, a0, a1);
+            if (r / 2 == 4) pipe_sync(P);
+            pipe_advance(P, r / 2, a0, a1);
             const float b0 = RELU ? relu(in[r]) : in[r];
             const float b1 = RELU ? relu(in[r + 1]) : in[r + 1];
             out[0] = MFMA(a0[0], b0, out[0]); out[1] = MFMA(a0[1], b0, out[1]);
+            pipe_mid_step(P, r / 2);
             out[2] = MFMA(a0[2], b0, out[2]); out[3] = MFMA(a0[3], b0, out[3]);
             out[0] = MFMA(a1[0], b1, out[0]); out[1] = MFMA(a1[1], b1, out[1]);
             out[2] = MFMA(a1[2], b1, out[2]); out[3] = MFMA(a1[3], b1, out[3]);
@@ -169,7 +240,52 @@ __device__ __forceinline__ void hidden_layer(const f32x16 (&in)[8], f32x16 (&out
     for (int t = 0; t < 8; ++t) tile_steps<8, RELU>(in[t], out, P);
 }
 
+// sin and cos of x for |x| <= 2^11 (the encodings reach ~1.25e3 rad): k = rint(x * 2/pi), three-constant Cody-Waite
+// reduction with FMA (x - k*pi/2 is exact in the first step), Cephes sinf/cosf minimax polynomials on [-pi/4, pi/4],
+// quadrant fix-up by sign-bit arithmetic.  Branch-free; max error 1.6 ulp over the whole range (tools/check_sincos.py).
+__device__ __forceinline__ void fast_sincos(float x, float *s_out, float *c_out) {
+#if NERF_FAST_SINCOS
+    const float k = __builtin_rintf(x * 0.636619772f);
+    float r = fmaf(k, -1.5707963705062866f, x);
+    r = fmaf(k, 4.371138828673793e-08f, r);
+    r = fmaf(k, 1.7763568394002505e-15f, r);
+    const float r2 = r * r;
+    float ps = fmaf(r2, -1.9515295891e-4f, 8.3321608736e-3f);
+    ps = fmaf(r2, ps, -1.6666654611e-1f);
+    const float s = fmaf(r * r2, ps, r);
+    float pc = fmaf(r2, 2.443315711809948e-5f, -1.388731625493765e-3f);
+    pc = fmaf(r2, pc, 4.166664568298827e-2f);
+    const float c = fmaf(r2 * r2, pc, fmaf(r2, -0.5f, 1.0f));
+    const uint32_t q = (uint32_t)(int)k;
+    const bool swap = (q & 1u) != 0;
+    const uint32_t sb = __builtin_bit_cast(uint32_t, swap ? c : s) ^ ((q & 2u) << 30);
+    const uint32_t cb = __builtin_bit_cast(uint32_t, swap ? s : c) ^ (((q + 1u) & 2u) << 30);
+    *s_out = __builtin_bit_cast(float, sb);
+    *c_out = __builtin_bit_cast(float, cb);
+#else
+    sincosf(x, s_out, c_out);
+#endif
+}
+
 __device__ __forceinline__ float xhalf_sum(float v) { return v + __shfl_xor(v, 32, 64); }
+
+// alpha head on the VALU: sigma = relu(b + sum_F w[F] relu(h8[F]))  (src/network.rs:216)
+__device__ __forceinline__ float alpha_head(const f32x16 (&Y)[8], const LDS_AS float *small, int h) {
+    const LDS_AS f32x4 *w = (const LDS_AS f32x4 *)(small + kAlphaWOff + h * 128);
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 wv = w[t * 4 + q];
+            a0 = fmaf(wv[0], relu(Y[t][4 * q + 0]), a0);
+            a1 = fmaf(wv[1], relu(Y[t][4 * q + 1]), a1);
+            a2 = fmaf(wv[2], relu(Y[t][4 * q + 2]), a2);
+            a3 = fmaf(wv[3], relu(Y[t][4 * q + 3]), a3);
+        }
+    }
+    return fmaxf(xhalf_sum((a0 + a1) + (a2 + a3)) + small[kMiscOff + 0], 0.f);
+}
 
 } // namespace
 
@@ -194,41 +310,63 @@ __global__ __launch_bounds__(256, 1) void nerf_mlp_kernel(const MlpArgs A) {
 
     Pipe P;
     P.lane16 = lane16;
-    P.ring_lo = lds + lane16;
-    P.ring_hi = lds + kRingSlots * kChunkBytes + lane16;
+    P.ring_lane = lds + lane16;
     P.ring_addr = (uint32_t)(uintptr_t)lds + wave * 4096;
     P.wr_slot_off = 0;
     P.next_off = 0;
     P.stream_bytes = (FULL ? kChunksFull : kChunksSigma) * kChunkBytes;
     P.gbase = (const char *)A.wstream + wave * 4096;
     __syncthreads();
-    pipe_issue(P);
-    pipe_issue(P);
+#pragma unroll
+    for (int c = 0; c < kRingSlots - 1; ++c) pipe_issue(P);
     asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-    P.rd = P.ring_lo;
-    {
-        f32x4 d0, d1;
-        pipe_advance(P, d0, d1); // prime: operands of macro-step 0
-    }
+    unsigned long long clk0 = 0, rt0 = 0;
+    if (A.clock_out) { clk0 = __builtin_amdgcn_s_memtime(); rt0 = __builtin_amdgcn_s_memrealtime(); }
+    P.rd_slot_off = 0;
+    P.rd_base = P.ring_lane;
+    P.a0 = *(const LDS_AS f32x4 *)(P.rd_base); // prime: operands of macro-step 0
+    P.a1 = *(const LDS_AS f32x4 *)(P.rd_base + 1024);
+
+    // Raw per-point inputs: 6 floats.  MODE_POINTS: position + direction as given (src/network.rs:197).
+    // MODE_RAYS: (t, unused, unused) + the ray's unit direction; p = origin + dir_hat * t is formed at use with the
+    // multiply and the add rounded separately (src/lib.rs:396 / :436).
+    struct RawIn { float a, b, c, dx, dy, dz; };
+    auto load_raw = [&](int tile_idx) -> RawIn {
+        RawIn r;
+        int i = tile_idx * kPointsPerBlock + wave * kPointsPerWave + p;
+        i = i < A.n_points ? i : A.n_points - 1; // clamp: the padding lanes of the last tile and the look-ahead tile
+        if (MODE == MLP_MODE_POINTS) {
+            r.a = A.pts_soa[i]; r.b = A.pts_soa[(size_t)A.n_points + i]; r.c = A.pts_soa[2 * (size_t)A.n_points + i];
+            r.dx = A.dirs_aos[3 * (size_t)i]; r.dy = A.dirs_aos[3 * (size_t)i + 1]; r.dz = A.dirs_aos[3 * (size_t)i + 2];
+        } else {
+            const int ray = i / A.samples_per_ray;
+            r.a = A.t[i]; r.b = 0.f; r.c = 0.f;
+            r.dx = A.ray_dirs[3 * (size_t)ray]; r.dy = A.ray_dirs[3 * (size_t)ray + 1]; r.dz = A.ray_dirs[3 * (size_t)ray + 2];
+        }
+        return r;
+    };
 
     const int n_tiles = (A.n_points + kPointsPerBlock - 1) / kPointsPerBlock;
+#if NERF_PREFETCH_INPUTS
+    RawIn nxt = load_raw(blockIdx.x);
+#endif
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const int i = tile * kPointsPerBlock + wave * kPointsPerWave + p;
         const bool valid = i < A.n_points;
-        const int ii = valid ? i : (A.n_points - 1);
-
-        // ---- inputs (src/lib.rs:396 / :436: p = origin + dir_hat * t, mul and add rounded separately)
-        float px, py, pz, dx, dy, dz;
+#if NERF_PREFETCH_INPUTS
+        const RawIn in = nxt;
+        nxt = load_raw(tile + gridDim.x); // consumed one tile (~250 us) later
+#else
+        const RawIn in = load_raw(tile);
+#endif
+        float px, py, pz;
+        const float dx = in.dx, dy = in.dy, dz = in.dz;
         if (MODE == MLP_MODE_POINTS) {
-            px = A.pts_soa[ii]; py = A.pts_soa[(size_t)A.n_points + ii]; pz = A.pts_soa[2 * (size_t)A.n_points + ii];
-            dx = A.dirs_aos[3 * (size_t)ii]; dy = A.dirs_aos[3 * (size_t)ii + 1]; dz = A.dirs_aos[3 * (size_t)ii + 2];
+            px = in.a; py = in.b; pz = in.c;
         } else {
-            const int ray = ii / A.samples_per_ray;
-            const float t = A.t[ii];
-            dx = A.ray_dirs[3 * (size_t)ray]; dy = A.ray_dirs[3 * (size_t)ray + 1]; dz = A.ray_dirs[3 * (size_t)ray + 2];
-            px = __fadd_rn(A.origin[0], __fmul_rn(dx, t));
-            py = __fadd_rn(A.origin[1], __fmul_rn(dy, t));
-            pz = __fadd_rn(A.origin[2], __fmul_rn(dz, t));
+            px = __fadd_rn(A.origin[0], __fmul_rn(dx, in.a));
+            py = __fadd_rn(A.origin[1], __fmul_rn(dy, in.a));
+            pz = __fadd_rn(A.origin[2], __fmul_rn(dz, in.a));
         }
 
         // ---- positional encoding of the point: this lane-half's 32 slots (src/network.rs:263-292)
@@ -239,9 +377,9 @@ __global__ __launch_bounds__(256, 1) void nerf_mlp_kernel(const MlpArgs A) {
 #pragma unroll
             for (int o = 0; o < 5; ++o) {
                 float s, c;
-                sincosf(f * px, &s, &c); E[(6 * o + 0) >> 4][(6 * o + 0) & 15] = s; E[(6 * o + 3) >> 4][(6 * o + 3) & 15] = c;
-                sincosf(f * py, &s, &c); E[(6 * o + 1) >> 4][(6 * o + 1) & 15] = s; E[(6 * o + 4) >> 4][(6 * o + 4) & 15] = c;
-                sincosf(f * pz, &s, &c); E[(6 * o + 2) >> 4][(6 * o + 2) & 15] = s; E[(6 * o + 5) >> 4][(6 * o + 5) & 15] = c;
+                fast_sincos(f * px, &s, &c); E[(6 * o + 0) >> 4][(6 * o + 0) & 15] = s; E[(6 * o + 3) >> 4][(6 * o + 3) & 15] = c;
+                fast_sincos(f * py, &s, &c); E[(6 * o + 1) >> 4][(6 * o + 1) & 15] = s; E[(6 * o + 4) >> 4][(6 * o + 4) & 15] = c;
+                fast_sincos(f * pz, &s, &c); E[(6 * o + 2) >> 4][(6 * o + 2) & 15] = s; E[(6 * o + 5) >> 4][(6 * o + 5) & 15] = c;
                 f *= 2.0f;
             }
             E[1][14] = h ? pz : px;
@@ -254,6 +392,32 @@ __global__ __launch_bounds__(256, 1) void nerf_mlp_kernel(const MlpArgs A) {
         load_bias<8>(X, small + kBiasOff + 0 * 256, h);
         tile_steps<8, false>(E[0], X, P);
         tile_steps<8, false>(E[1], X, P);
+
+        float sigma = 0.f;
+#if NERF_LOOP_LAYERS
+        // dense1..dense7 + bottleneck as FOUR passes over one pair of layer bodies (X -> Y, Y -> X).  The straight-line
+        // form of the network is ~270 KB of code per tile, four times the 64 KB instruction cache, and ran ~6 cycles
+        // per MFMA slower than the same stream looped; the loop body (~48 KB) stays cache-resident.
+        //   p = 0: dense1, dense2   p = 1: dense3, dense4   p = 2: dense5 (skip: encoding steps first), dense6
+        //   p = 3: dense7, [alpha head], bottleneck (full kernels only)
+#pragma nounroll
+        for (int p2 = 0; p2 < 4; ++p2) {
+            load_bias<8>(Y, small + kBiasOff + (1 + 2 * p2) * 256, h);
+            if (p2 == 2) { // dense5 = [encoding ; h4] (src/network.rs:209-210): the 32 encoding k-steps come first
+                tile_steps<8, false>(E[0], Y, P);
+                tile_steps<8, false>(E[1], Y, P);
+            }
+#pragma unroll
+            for (int t = 0; t < 8; ++t) tile_steps<8, true>(X[t], Y, P);
+            if (p2 == 3) {
+                sigma = alpha_head(Y, small, h);
+                if (!FULL) break;
+            }
+            load_bias<8>(X, small + kBiasOff + (2 + 2 * p2) * 256, h); // p2 == 3: bottleneck (no activation, :218)
+#pragma unroll
+            for (int t = 0; t < 8; ++t) tile_steps<8, true>(Y[t], X, P);
+        }
+#else
         // dense1..4
         hidden_layer<true>(X, Y, small + kBiasOff + 1 * 256, P, h);
         hidden_layer<true>(Y, X, small + kBiasOff + 2 * 256, P, h);
@@ -268,30 +432,12 @@ __global__ __launch_bounds__(256, 1) void nerf_mlp_kernel(const MlpArgs A) {
         // dense6, dense7
         hidden_layer<true>(Y, X, small + kBiasOff + 6 * 256, P, h);
         hidden_layer<true>(X, Y, small + kBiasOff + 7 * 256, P, h);
-
-        // alpha head on the VALU: sigma = relu(b + sum_F w[F] relu(h8[F]))  (src/network.rs:216)
-        float sigma;
-        {
-            const LDS_AS f32x4 *w = (const LDS_AS f32x4 *)(small + kAlphaWOff + h * 128);
-            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-#pragma unroll
-            for (int t = 0; t < 8; ++t) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const f32x4 wv = w[t * 4 + q];
-                    a0 = fmaf(wv[0], fmaxf(Y[t][4 * q + 0], 0.f), a0);
-                    a1 = fmaf(wv[1], fmaxf(Y[t][4 * q + 1], 0.f), a1);
-                    a2 = fmaf(wv[2], fmaxf(Y[t][4 * q + 2], 0.f), a2);
-                    a3 = fmaf(wv[3], fmaxf(Y[t][4 * q + 3], 0.f), a3);
-                }
-            }
-            sigma = fmaxf(xhalf_sum((a0 + a1) + (a2 + a3)) + small[kMiscOff + 0], 0.f);
-        }
+        sigma = alpha_head(Y, small, h);
+        if (FULL) hidden_layer<true>(Y, X, small + kBiasOff + 8 * 256, P, h); // bottleneck (no activation, :218)
+#endif
         if (valid && h == 0) A.sigma_out[i] = sigma;
 
         if (FULL) {
-            // bottleneck (no activation, src/network.rs:218): Y -> X
-            hidden_layer<true>(Y, X, small + kBiasOff + 8 * 256, P, h);
             // direction encoding: 16 slots per lane-half (src/network.rs:294-330)
             f32x16 D;
             {
@@ -299,9 +445,9 @@ __global__ __launch_bounds__(256, 1) void nerf_mlp_kernel(const MlpArgs A) {
 #pragma unroll
                 for (int o = 0; o < 2; ++o) {
                     float s, c;
-                    sincosf(f * dx, &s, &c); D[6 * o + 0] = s; D[6 * o + 3] = c;
-                    sincosf(f * dy, &s, &c); D[6 * o + 1] = s; D[6 * o + 4] = c;
-                    sincosf(f * dz, &s, &c); D[6 * o + 2] = s; D[6 * o + 5] = c;
+                    fast_sincos(f * dx, &s, &c); D[6 * o + 0] = s; D[6 * o + 3] = c;
+                    fast_sincos(f * dy, &s, &c); D[6 * o + 1] = s; D[6 * o + 4] = c;
+                    fast_sincos(f * dz, &s, &c); D[6 * o + 2] = s; D[6 * o + 5] = c;
                     f *= 2.0f;
                 }
                 D[12] = h ? 0.f : dx; D[13] = h ? 0.f : dy; D[14] = h ? 0.f : dz; D[15] = 0.f;
@@ -323,10 +469,10 @@ __global__ __launch_bounds__(256, 1) void nerf_mlp_kernel(const MlpArgs A) {
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         const f32x4 wv = w[t * 4 + q];
-                        a0 = fmaf(wv[0], fmaxf(V[t][4 * q + 0], 0.f), a0);
-                        a1 = fmaf(wv[1], fmaxf(V[t][4 * q + 1], 0.f), a1);
-                        a2 = fmaf(wv[2], fmaxf(V[t][4 * q + 2], 0.f), a2);
-                        a3 = fmaf(wv[3], fmaxf(V[t][4 * q + 3], 0.f), a3);
+                        a0 = fmaf(wv[0], relu(V[t][4 * q + 0]), a0);
+                        a1 = fmaf(wv[1], relu(V[t][4 * q + 1]), a1);
+                        a2 = fmaf(wv[2], relu(V[t][4 * q + 2]), a2);
+                        a3 = fmaf(wv[3], relu(V[t][4 * q + 3]), a3);
                     }
                 }
                 const float v = xhalf_sum((a0 + a1) + (a2 + a3)) + small[kMiscOff + 1 + ch];
@@ -341,6 +487,10 @@ __global__ __launch_bounds__(256, 1) void nerf_mlp_kernel(const MlpArgs A) {
     }
     // drain the (unused) prefetches before the LDS allocation is released
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (A.clock_out && tid == 0) { // diagnostic: shader clock = d(memtime) / d(memrealtime) x 100 MHz
+        A.clock_out[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - clk0;
+        A.clock_out[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - rt0;
+    }
 }
 
 template <bool FULL, int MODE>

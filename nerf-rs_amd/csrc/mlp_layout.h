@@ -19,7 +19,10 @@ namespace nerfmlp {
 
 constexpr int kChunkBytes = 16384;
 constexpr int kChunkFloats = kChunkBytes / 4;
-constexpr int kRingSlots = 3;
+#ifndef NERF_RING_SLOTS
+#define NERF_RING_SLOTS 3
+#endif
+constexpr int kRingSlots = NERF_RING_SLOTS; // >= 3; chunk c + kRingSlots - 1 is DMA'd while chunk c is consumed
 constexpr int kPointsPerWave = 32;
 constexpr int kWavesPerBlock = 4;
 constexpr int kPointsPerBlock = kPointsPerWave * kWavesPerBlock;

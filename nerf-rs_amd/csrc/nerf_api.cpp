@@ -55,6 +55,8 @@ struct nerf_ctx {
     float *d_out = nullptr; size_t out_floats = 0;       // host-pointer render output staging
     // scratch for forward_batch / stage calls
     void *d_scratch = nullptr; size_t scratch_bytes = 0;
+    unsigned long long *d_clock = nullptr; // diagnostic: per-workgroup {cycles, 100 MHz ticks} of the last fine-MLP launch
+    bool clock_valid = false;
     size_t max_rays_per_pass = (size_t)1 << 20;
     std::vector<hipEvent_t> ev_pool;
     std::vector<EvPair> last_render; // events of the last render
@@ -254,6 +256,8 @@ int render_device(nerf_ctx *c, const nerf_camera *cam, const nerf_render_opts *o
         a.wstream = NF.wstream; a.small_params = NF.small;
         a.n_points = n_rays * M; a.samples_per_ray = M; a.t = t_fine;
         a.sigma_out = c->d_sf; a.rgb_out = c->d_rgbf;
+        a.clock_out = c->d_clock; // NULL unless NERF_DEBUG_CLOCK=1
+        c->clock_valid = c->d_clock != nullptr;
         {
             Timed t(c, st, 1, (uint64_t)a.n_points, timing);
             HIP_TRY(c, nerf_mlp_launch(a, true, c->n_cus, st));
@@ -331,6 +335,9 @@ int nerf_create(int device_id, nerf_ctx **out) {
         const long long v = atoll(env);
         if (v > 0) c->max_rays_per_pass = (size_t)v;
     }
+    if (const char *env = getenv("NERF_DEBUG_CLOCK")) {
+        if (atoi(env) > 0 && hipMalloc((void **)&c->d_clock, (size_t)c->n_cus * 2 * sizeof(unsigned long long)) != hipSuccess) c->d_clock = nullptr;
+    }
     hipError_t e1 = nerf_mlp_init();
     hipError_t e2 = e1 == hipSuccess ? sampling_init() : e1;
     hipError_t e3 = e2 == hipSuccess ? hipStreamCreate(&c->stream) : e2;
@@ -351,6 +358,7 @@ void nerf_destroy(nerf_ctx *c) {
     float *ptrs[] = {c->d_dirs, c->d_tc, c->d_sc, c->d_rgbc, c->d_tf, c->d_sf, c->d_rgbf, c->d_rayfb, c->d_out};
     for (float *p : ptrs) if (p) (void)hipFree(p);
     if (c->d_scratch) (void)hipFree(c->d_scratch);
+    if (c->d_clock) (void)hipFree(c->d_clock);
     recycle_render(c);
     recycle_dominant(c, 0);
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
@@ -512,6 +520,21 @@ int nerf_kernel_time_query(nerf_ctx *c, double *ms, uint64_t *points, uint32_t *
         c->last_render.erase(std::remove_if(c->last_render.begin(), c->last_render.end(), [](const EvPair &p) { return p.kind == 3; }), c->last_render.end());
         recycle_dominant(c, 0);
     }
+    return NERF_OK;
+}
+
+int nerf_debug_shader_clock_mhz(nerf_ctx *c, double *mhz) {
+    if (!c || !mhz) return fail(c, NERF_ERR_INVALID, "NULL argument");
+    if (!c->d_clock || !c->clock_valid) return fail(c, NERF_ERR_STATE, "set NERF_DEBUG_CLOCK=1 before nerf_create and render a frame first");
+    DeviceGuard dg(c->device);
+    std::vector<unsigned long long> h((size_t)c->n_cus * 2);
+    HIP_TRY(c, hipDeviceSynchronize());
+    HIP_TRY(c, hipMemcpy(h.data(), c->d_clock, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    std::vector<double> f;
+    for (int i = 0; i < c->n_cus; ++i) if (h[2 * i + 1] > 0) f.push_back(100.0 * (double)h[2 * i] / (double)h[2 * i + 1]);
+    if (f.empty()) return fail(c, NERF_ERR_STATE, "no clock samples");
+    std::sort(f.begin(), f.end());
+    *mhz = f[f.size() / 2];
     return NERF_OK;
 }
 
