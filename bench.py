@@ -34,8 +34,12 @@ def host_cores():
     return max(1, min(n, 32))
 
 
-def cpu_baseline(width, height, n_coarse, n_fine, seed, block_rows=2):
-    """Oracle (kind: "port") on the host cores: one 8x8 block per thread, forward_fallback's loop order."""
+def cpu_baseline(width, height, n_coarse, n_fine, seed, naive_too=False):
+    """The CPU oracle (kind "port": a C restatement of the reference's algorithm, oracle/nerf_oracle.c) on this host's
+    cores, on a bounded crop of the same frame.  Default: the oracle's cache-blocked loop nest (bit-identical results
+    to the reference's nest, ~30-300x faster).  --cpu-naive additionally times forward_fallback's own loop order
+    (src/network.rs:134-143) on one 8x2-ray task per thread; measured on the round-1 GPU box (16 threads): 9.07 rays/s
+    with 8x8 blocks (113 s), 2.27 rays/s with 8x2 strips (113 s) -- too slow for a default run."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle_py as O
     scene = os.path.join(ROOT, "lego_rust")
@@ -43,25 +47,26 @@ def cpu_baseline(width, height, n_coarse, n_fine, seed, block_rows=2):
     co, fi = O.Net(os.path.join(scene, "coarse")), O.Net(os.path.join(scene, "fine"))
     cam = O.camera_from_samples(S, width, height)
     cores = host_cores()
-    # One task per thread, centred on the model.  The reference's rayon task is an 8x8 block (src/lib.rs:491,533), but
-    # in the reference's loop order one such block takes ~110 s on this class of host (measured: 9.07 rays/s on 16
-    # threads, 16 blocks, round-1 run), so the default sample uses 8x2-ray strips (16 rays, B = 1024 / 3072 columns
-    # per forward_batch) to stay near 30 s; --cpu-block-rows 8 times the full 8x8 blocks.
-    bh = max(d for d in range(1, int(cores ** 0.5) + 1) if cores % d == 0)  # bw * bh == cores exactly
-    bw = cores // bh
-    crop = (width // 2 - 4 * bw, height // 2 - (block_rows * bh) // 2, 8 * bw, block_rows * bh)
-    n_rays = crop[2] * crop[3]
-    t0 = time.time()
-    O.render_image(co, fi, cam, O.make_opts(n_coarse, n_fine, crop=crop, seed=seed, naive=True, threads=cores))
-    dt = time.time() - t0
+    side = 8 * max(4, int(round((cores * 16) ** 0.5)))  # ~1000 rays (16 8x8 blocks) per thread: ~10-25 s
+    side = min(side, (min(width, height) // 8) * 8)
+    crop = ((width - side) // 2, (height - side) // 2, side, side)
+    n_rays = side * side
     t0 = time.time()
     O.render_image(co, fi, cam, O.make_opts(n_coarse, n_fine, crop=crop, seed=seed, naive=False, threads=cores))
-    dt_blocked = time.time() - t0
-    return {"value": n_rays / dt, "unit": "rays/s", "cores": cores, "kind": "port",
-            "sample": f"{crop[2]}x{crop[3]} crop at ({crop[0]},{crop[1]}) of the {width}x{height} frame = {n_rays} rays "
-                      f"({bw * bh} tasks of 8x{block_rows} rays, one per thread), {n_coarse}+{n_fine} samples, reference loop order "
-                      f"(src/network.rs:134-143), {dt:.1f} s; baseline, not target",
-            "cache_blocked_variant_rays_per_s": n_rays / dt_blocked}
+    dt = time.time() - t0
+    out = {"value": n_rays / dt, "unit": "rays/s", "cores": cores, "kind": "port",
+           "sample": f"{side}x{side} crop at ({crop[0]},{crop[1]}) of the {width}x{height} frame = {n_rays} rays in 8x8 blocks "
+                     f"(the reference's rayon task, src/lib.rs:491,533) over {cores} threads, {n_coarse}+{n_fine} samples, "
+                     f"cache-blocked loop nest (bit-identical to the reference's), {dt:.1f} s; baseline, not target",
+           "reference_loop_order_rays_per_s": None}
+    if naive_too:
+        bh = max(d for d in range(1, int(cores ** 0.5) + 1) if cores % d == 0)
+        bw = cores // bh
+        c2 = (width // 2 - 4 * bw, height // 2 - bh, 8 * bw, 2 * bh)
+        t0 = time.time()
+        O.render_image(co, fi, cam, O.make_opts(n_coarse, n_fine, crop=c2, seed=seed, naive=True, threads=cores))
+        out["reference_loop_order_rays_per_s"] = c2[2] * c2[3] / (time.time() - t0)
+    return out
 
 
 def main():
@@ -75,7 +80,7 @@ def main():
     ap.add_argument("--fine", type=int, default=128)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-block-rows", type=int, default=2, help="rows of each 8-wide CPU task (8 = the reference's 8x8 block)")
+    ap.add_argument("--cpu-naive", action="store_true", help="also time the reference's own loop order (minutes)")
     args = ap.parse_args()
 
     import torch
@@ -147,7 +152,7 @@ def main():
                          "points_per_launch": pts_dom // max(n_dom, 1), "flop_per_point": N.FLOP_PER_POINT_FULL},
         }
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(args.width, args.height, args.coarse, args.fine, args.seed, args.cpu_block_rows)
+            line["cpu_baseline"] = cpu_baseline(args.width, args.height, args.coarse, args.fine, args.seed, args.cpu_naive)
         print(json.dumps(line), flush=True)
     del out
     r.close()
