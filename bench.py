@@ -21,6 +21,22 @@ sys.path.insert(0, ROOT)
 PEAK_FP32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 
 
+def pmc_traffic_bytes():
+    """HBM bytes per launch of the fine-MLP kernel from the committed rocprofv3 PMC passes (profiles/*_pmc_summary.csv:
+    separate FETCH_SIZE / WRITE_SIZE runs; FETCH_SIZE doubled per the gfx950 note in MI355X_MICROARCH.md).  The kernel is
+    MFMA-bound; this is reported for completeness (algorithmic: 20 B/point in+out = 2.46 GB per 122.88 M-point launch)."""
+    import csv
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.csv")))
+    if not files:
+        return None
+    for row in csv.DictReader(open(files[-1])):
+        if row["kernel"].startswith("void nerf_mlp_kernel<true") and float(row.get("FETCH_SIZE", 0)) > 0:
+            n = max(int(row["dispatches"]), 1)
+            return (2.0 * float(row["FETCH_SIZE"]) + float(row["WRITE_SIZE"])) * 1024.0 / n
+    return None
+
+
 def host_cores():
     """Threads to use on the host: the affinity mask, capped by the cgroup CPU quota (the GPU box gives a share of a
     large host; oversubscribing it would measure the scheduler, not the code) and by 32."""
@@ -47,7 +63,7 @@ def cpu_baseline(width, height, n_coarse, n_fine, seed, naive_too=False):
     co, fi = O.Net(os.path.join(scene, "coarse")), O.Net(os.path.join(scene, "fine"))
     cam = O.camera_from_samples(S, width, height)
     cores = host_cores()
-    side = 8 * max(4, int(round((cores * 16) ** 0.5)))  # ~1000 rays (16 8x8 blocks) per thread: ~10-25 s
+    side = 8 * max(4, int(round((cores * 48) ** 0.5)))  # ~3000 rays (48 8x8 blocks) per thread: ~15 s on the GPU box
     side = min(side, (min(width, height) // 8) * 8)
     crop = ((width - side) // 2, (height - side) // 2, side, side)
     n_rays = side * side
@@ -94,8 +110,12 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU with torch.distributed.run")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm
+    # NERF_BENCH_FORCE_DIST=1 drives the N > 1 code path (process group, band split, RCCL all-gather) at world size 1
+    use_dist = world > 1 or os.environ.get("NERF_BENCH_FORCE_DIST") == "1"
+    if use_dist:
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)  # nccl == RCCL on ROCm
 
     scene = os.path.join(ROOT, "lego_rust")
     r = N.Renderer(local_rank)
@@ -105,13 +125,13 @@ def main():
     frame = torch.empty((args.height, args.width, 3), dtype=torch.float32, device=dev)
 
     def step():
-        if world == 1:
+        if not use_dist:
             N.render_image(r.coarse, r.fine, cam, args.fine, seed=args.seed, device_out=frame.data_ptr(), stream=stream)
             return frame
         return N.render_image_distributed(r.coarse, r.fine, cam, args.fine, seed=args.seed, return_tensor=True)
 
     def fence():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -126,7 +146,7 @@ def main():
     dt = time.perf_counter() - t0
     ms_dom, pts_dom, n_dom = r.kernel_time_query(reset=True)
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
 
@@ -135,7 +155,7 @@ def main():
         flop_ray = N.flop_per_ray(args.coarse, args.fine)
         value = n_rays * args.steps / dt
         ach = pts_dom * N.FLOP_PER_POINT_FULL / (ms_dom * 1e-3) / 1e12 if ms_dom > 0 else 0.0
-        line = {
+        line = {  # noqa: E501
             "metric": "rays/sec, lego 800x800 (64 coarse + 128 fine samples per ray)", "value": value, "unit": "rays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
@@ -146,7 +166,7 @@ def main():
                        "rays_per_step": n_rays, "flop_per_ray": flop_ray, "seed": args.seed,
                        "whole_job_fraction_of_fp32_mfma_roofline": value * flop_ray / (world * PEAK_FP32_MFMA_TFLOPS * 1e12)},
             "roofline": {"bound": "mfma", "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": ach / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                         "frac": ach / PEAK_FP32_MFMA_TFLOPS, "traffic": pmc_traffic_bytes(),
                          "kernel": "nerf_mlp_kernel<FULL=true, MODE_RAYS> (fine network)",
                          "launches": n_dom, "avg_launch_ms": ms_dom / max(n_dom, 1),
                          "points_per_launch": pts_dom // max(n_dom, 1), "flop_per_point": N.FLOP_PER_POINT_FULL},
@@ -156,7 +176,7 @@ def main():
         print(json.dumps(line), flush=True)
     del out
     r.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

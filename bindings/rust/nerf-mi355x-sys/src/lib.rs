@@ -1,0 +1,92 @@
+//! Raw bindings to libnerf_mi355x.so.  One-to-one with include/nerf_mi355x.h (ABI version 1); layouts are `#[repr(C)]`
+//! mirrors of `nerf_camera`, `nerf_render_opts`, `nerf_stats`.
+#![allow(non_camel_case_types)]
+use std::os::raw::{c_char, c_int, c_void};
+
+#[repr(C)]
+pub struct nerf_ctx {
+    _private: [u8; 0],
+}
+
+/// `struct Camera` of the reference (src/lib.rs:197-211); `samples_per_ray` lives in `nerf_render_opts::n_coarse`.
+#[repr(C)]
+#[derive(Clone, Copy, Debug, Default)]
+pub struct nerf_camera {
+    pub nx: i32,
+    pub ny: i32,
+    pub alpha_width: f32,
+    pub alpha_height: f32,
+    pub pos: [f32; 3],
+    pub dir: [f32; 3],
+    pub up: [f32; 3],
+    pub near: f32,
+    pub far: f32,
+}
+
+#[repr(C)]
+#[derive(Clone, Copy, Debug, Default)]
+pub struct nerf_render_opts {
+    pub n_coarse: i32,
+    pub n_fine: i32,
+    pub coarse_only: i32,
+    pub crop_x0: i32,
+    pub crop_y0: i32,
+    pub crop_w: i32,
+    pub crop_h: i32,
+    pub ssaa: i32,
+    pub seed: u64,
+    pub reserved: [i32; 4],
+}
+
+#[repr(C)]
+#[derive(Clone, Copy, Debug, Default)]
+pub struct nerf_stats {
+    pub n_rays: u64,
+    pub n_coarse_points: u64,
+    pub n_fine_points: u64,
+    pub ms_total: f64,
+    pub ms_coarse_mlp: f64,
+    pub ms_fine_mlp: f64,
+    pub ms_other: f64,
+    pub n_mlp_launches: u32,
+    pub n_passes: u32,
+}
+
+pub const NERF_OK: c_int = 0;
+pub const NERF_NET_COARSE: c_int = 0;
+pub const NERF_NET_FINE: c_int = 1;
+
+extern "C" {
+    pub fn nerf_abi_version() -> c_int;
+    pub fn nerf_create(device_id: c_int, out: *mut *mut nerf_ctx) -> c_int;
+    pub fn nerf_destroy(ctx: *mut nerf_ctx);
+    pub fn nerf_last_error(ctx: *const nerf_ctx) -> *const c_char;
+    pub fn nerf_device_info(ctx: *const nerf_ctx, n_cus: *mut c_int, arch_name: *mut c_char, len: usize) -> c_int;
+    pub fn nerf_load_network_dir(ctx: *mut nerf_ctx, which: c_int, dir: *const c_char) -> c_int;
+    pub fn nerf_load_network_tensors(ctx: *mut nerf_ctx, which: c_int, n: c_int, names: *const *const c_char,
+                                     dims: *const i64, data: *const *const f32) -> c_int;
+    pub fn nerf_check_network_dir(dir: *const c_char) -> c_int;
+    pub fn nerf_forward_batch(ctx: *mut nerf_ctx, which: c_int, pts_soa: *const f32, dirs_aos: *const f32, n: usize,
+                              rgb_aos: *mut f32, sigma: *mut f32) -> c_int;
+    pub fn nerf_forward_batch_device(ctx: *mut nerf_ctx, which: c_int, d_pts_soa: *const f32, d_dirs_aos: *const f32,
+                                     n: usize, d_rgb_aos: *mut f32, d_sigma: *mut f32, stream: *mut c_void) -> c_int;
+    pub fn nerf_render_image(ctx: *mut nerf_ctx, cam: *const nerf_camera, opts: *const nerf_render_opts,
+                             rgb_out: *mut f32, stats: *mut nerf_stats) -> c_int;
+    pub fn nerf_render_image_device(ctx: *mut nerf_ctx, cam: *const nerf_camera, opts: *const nerf_render_opts,
+                                    d_rgb_out: *mut f32, stream: *mut c_void, stats: *mut nerf_stats) -> c_int;
+    pub fn nerf_kernel_time_query(ctx: *mut nerf_ctx, ms: *mut f64, points: *mut u64, n_launches: *mut u32, reset: c_int) -> c_int;
+    pub fn nerf_camera_from_json(json_path: *const c_char, width: c_int, height: c_int, out: *mut nerf_camera) -> c_int;
+    pub fn nerf_camera_from_values(near: f32, far: f32, origin: *const f32, forward: *const f32, up: *const f32,
+                                   hwf: *const f32, width: c_int, height: c_int, out: *mut nerf_camera) -> c_int;
+    pub fn nerf_save_ppm(path: *const c_char, width: c_int, height: c_int, rgb: *const f32) -> c_int;
+    pub fn nerf_quantize_rgb8(rgb: *const f32, n_pixels: usize, out: *mut u8);
+    pub fn nerf_stage_ray_dirs(ctx: *mut nerf_ctx, cam: *const nerf_camera, x0: c_int, y0: c_int, w: c_int, h: c_int,
+                               normalize: c_int, dirs_out: *mut f32) -> c_int;
+    pub fn nerf_stage_stratified(ctx: *mut nerf_ctx, cam: *const nerf_camera, x0: c_int, y0: c_int, w: c_int, h: c_int,
+                                 count: c_int, seed: u64, t_out: *mut f32) -> c_int;
+    pub fn nerf_stage_resample(ctx: *mut nerf_ctx, n_rays: usize, nc: c_int, nf: c_int, far: f32, seed: u64,
+                               pixel_index: *const u32, t_coarse: *const f32, sigma_coarse: *const f32, u: *const f32,
+                               w_out: *mut f32, cdf_out: *mut f32, t_new_out: *mut f32, t_fine_out: *mut f32) -> c_int;
+    pub fn nerf_stage_integrate(ctx: *mut nerf_ctx, n_rays: usize, n: c_int, far: f32, rgb_aos: *const f32,
+                                sigma: *const f32, t: *const f32, rgb_out: *mut f32, w_out: *mut f32) -> c_int;
+}

@@ -289,3 +289,37 @@ def test_ppm_of_full_frame(frame800, native, oracle, tmp_path):
     raw = p.read_bytes()
     assert raw[:15] == b"P6\n800 800\n255\n" and len(raw) == 15 + 800 * 800 * 3
     assert np.array_equal(np.frombuffer(raw[15:], np.uint8), oracle.quantize_rgb8(img).reshape(-1))
+
+
+# ---- scheduler: passes, CLI ------------------------------------------------------------------------------------------
+def test_multi_pass_render_is_bit_identical(renderer, native, samples, monkeypatch):
+    """The pass scheduler (nerf_api.cpp) cuts the frame into row passes that fit NERF_MAX_RAYS_PER_PASS; with per-pixel
+    RNG and no cross-ray state the image must not depend on the pass size (incl. passes of one ragged row)."""
+    cam = native.camera_from_samples(samples, 800, 800, 64)
+    crop = (300, 380, 211, 37)
+    one = native.render_image(renderer.coarse, renderer.fine, cam, 128, seed=2, crop=crop)
+    for cap in ("2000", "211", "50"):
+        monkeypatch.setenv("NERF_MAX_RAYS_PER_PASS", cap)
+        with native.Renderer(0) as r2:
+            r2.load_scene(SCENE)
+            img, st = native.render_image(r2.coarse, r2.fine, cam, 128, seed=2, crop=crop, return_stats=True)
+        assert st.n_passes == -(-37 // max(1, int(cap) // 211)) and np.array_equal(img, one)
+
+
+def test_cli_matches_library(renderer, native, samples, tmp_path):
+    """nerf_cli (the render_cli_image counterpart, src/lib.rs:647-677): default run = 256x256, 64 + 128 -> output.ppm."""
+    import subprocess
+    from conftest import ROOT
+    exe = os.path.join(ROOT, "nerf-rs_amd", "nerf_cli")
+    out = tmp_path / "output.ppm"
+    res = subprocess.run([exe, "--scene", SCENE, "--out", str(out)], capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0, res.stderr
+    assert "Rendering with 64 coarse samples and 128 fine samples per ray" in res.stdout       # src/lib.rs:660-663
+    assert "Starting image rendering..." in res.stdout and "Rendering completed in" in res.stdout
+    raw = out.read_bytes()
+    assert raw[:15] == b"P6\n256 256\n255\n" and len(raw) == 15 + 256 * 256 * 3
+    cam = native.camera_from_samples(samples, 256, 256, 64)
+    img = native.render_image(renderer.coarse, renderer.fine, cam, 128, seed=0)
+    assert np.array_equal(np.frombuffer(raw[15:], np.uint8), native.quantize_rgb8(img).reshape(-1))
+    bad = subprocess.run([exe, "--scene", str(tmp_path / "nope")], capture_output=True, text=True, timeout=60)
+    assert bad.returncode == 1 and "read shapes" in bad.stderr
