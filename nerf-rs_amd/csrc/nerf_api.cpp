@@ -196,7 +196,10 @@ int render_device(nerf_ctx *c, const nerf_camera *cam, const nerf_render_opts *o
     const int M = nc + nf;
     if ((size_t)M * 7 * 4 * sizeof(float) > 160 * 1024) return fail(c, NERF_ERR_INVALID, "too many samples per ray for the compositing kernel");
     const int RW = cw * s, RH = ch * s, RX0 = x0 * s, RY0 = y0 * s;
-    const size_t rows_per_pass = std::max<size_t>(1, std::min<size_t>(RH, c->max_rays_per_pass / (size_t)RW));
+    // a pass must keep rays * samples within int32 (kernel indices) as well as within the configured budget
+    const size_t pass_cap = std::min<size_t>(c->max_rays_per_pass, (size_t)0x3fffffff / (size_t)M);
+    if ((size_t)RW > pass_cap && (size_t)RW * M > (size_t)0x3fffffff) return fail(c, NERF_ERR_INVALID, "ray row too wide for one pass");
+    const size_t rows_per_pass = std::max<size_t>(1, std::min<size_t>(RH, pass_cap / (size_t)RW));
     if ((rc = ensure_workspace(c, rows_per_pass * RW, nc, M))) return rc;
     float *ray_out = d_out;
     if (s > 1) {
