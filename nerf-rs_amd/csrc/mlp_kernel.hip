@@ -44,6 +44,15 @@ using namespace nerfmlp;
 #define NERF_STR(x) NERF_STR2(x)
 // chunks allowed to stay in flight across the mid-chunk sync: kRingSlots - 3 (4 pieces each)
 #define NERF_SYNC_VMCNT ((NERF_RING_SLOTS - 3) * 4)
+#ifndef NERF_RELU_PIPE
+#define NERF_RELU_PIPE 0 // (measured slower, 89.0 % vs 92.3 %: interleaving VALU between MFMAs costs more than clustering it) 1: the next k-step's B operand (AGPR read + ReLU) is prepared between the current step's MFMAs
+#endif
+#ifndef NERF_RELU_GROUP
+#define NERF_RELU_GROUP 16 // (1: 92.1 %, 2: 93.4 %, 4: 94.1 %, 8: 94.3 %, 16: 94.4 % of the fp32 MFMA roofline) B operands (AGPR read + ReLU) are prepared for this many k-steps in ONE contiguous VALU burst
+#endif
+#ifndef NERF_LDS_GROUP
+#define NERF_LDS_GROUP 1 // A operands are fetched from LDS for this many macro-steps per burst (1, 2 or 4)
+#endif
 #ifndef NERF_LOOP_LAYERS
 #define NERF_LOOP_LAYERS 0 // (measured slower: 87.1 % vs 87.8 %; kept for the record) 1: dense1..7 + bottleneck as a runtime loop over 4 layer pairs (instruction-cache resident)
 #endif
@@ -65,7 +74,8 @@ struct Pipe {
     const LDS_AS char *rd_base; // LDS address (incl. lane*16) of the chunk the NEXT macro-step to fetch lives in
     const LDS_AS char *ring_lane; // ring base + lane*16
     uint32_t rd_slot_off;       // wave-uniform byte offset of that chunk's slot
-    f32x4 a0, a1;            // prefetched A operands of the current macro-step
+    f32x4 nx[2 * NERF_LDS_GROUP]; // prefetched A operands of the next group of macro-steps
+    f32x4 cu[2 * NERF_LDS_GROUP]; // A operands of the current group
     uint32_t ring_addr;      // LDS byte address of the ring + wave*4 KiB (DMA destination base)
     uint32_t wr_slot_off;    // byte offset of the slot the next DMA chunk goes to
     uint32_t next_off;       // byte offset in the stream of the next chunk to DMA
@@ -151,25 +161,33 @@ __device__ __forceinline__ void pipe_mid_step(Pipe &P, int ms) {
 // All in-chunk addressing is a per-chunk base + immediate offset: VALU instructions are NOT free next to fp32 MFMAs
 // (they share the vector datapath), so the ring arithmetic is one v_add per chunk plus scalar ops.
 __device__ __forceinline__ void pipe_advance(Pipe &P, int ms, f32x4 &a0, f32x4 &a1) {
-    a0 = P.a0;
-    a1 = P.a1;
-    int nxt = ms + 1;
-    if (nxt == 8) {
-        uint32_t off = P.rd_slot_off + kChunkBytes;
-        off = (off == kRingSlots * kChunkBytes) ? 0u : off;
-        P.rd_slot_off = off;
-        P.rd_base = P.ring_lane + off;
-        nxt = 0;
-    }
+    constexpr int LG = NERF_LDS_GROUP;
+    if (ms % LG == 0) {
+#pragma unroll
+        for (int j = 0; j < 2 * LG; ++j) P.cu[j] = P.nx[j];
+        int nxt = ms + LG;
+        if (nxt == 8) {
+            uint32_t off = P.rd_slot_off + kChunkBytes;
+            off = (off == kRingSlots * kChunkBytes) ? 0u : off;
+            P.rd_slot_off = off;
+            P.rd_base = P.ring_lane + off;
+            nxt = 0;
+        }
+#pragma unroll
+        for (int j = 0; j < LG; ++j) {
 #if NERF_DIAG_NO_LDS
-    asm volatile("" : "+v"(P.a0), "+v"(P.a1));
+            asm volatile("" : "+v"(P.nx[2 * j]), "+v"(P.nx[2 * j + 1]));
 #else
-    P.a0 = *(const LDS_AS f32x4 *)(P.rd_base + nxt * 2048);
-    P.a1 = *(const LDS_AS f32x4 *)(P.rd_base + nxt * 2048 + 1024);
+            P.nx[2 * j] = *(const LDS_AS f32x4 *)(P.rd_base + (nxt + j) * 2048);
+            P.nx[2 * j + 1] = *(const LDS_AS f32x4 *)(P.rd_base + (nxt + j) * 2048 + 1024);
 #endif
-    // keep the two ds_reads of the NEXT macro-step ahead of this macro-step's MFMAs (otherwise hipcc sinks
-    // them below the MFMAs into the same registers and exposes the LDS latency every 8 MFMAs)
-    __builtin_amdgcn_sched_barrier(0);
+        }
+        // keep the ds_reads of the NEXT group ahead of this group's MFMAs (otherwise hipcc sinks them below the
+        // MFMAs into the same registers and exposes the LDS latency)
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    a0 = P.cu[2 * (ms % LG)];
+    a1 = P.cu[2 * (ms % LG) + 1];
 }
 
 // ReLU as a signed-integer max on the bit pattern: one v_max_i32 (fmaxf costs an extra canonicalising v_max), and --
@@ -188,13 +206,72 @@ __device__ __forceinline__ float relu(float v) {
 template <int NT, bool RELU>
 __device__ __forceinline__ void tile_steps(const f32x16 &in, f32x16 (&out)[NT], Pipe &P) {
     static_assert(NT == 8 || NT == 4, "NT");
+#if NERF_RELU_PIPE
+    // B operands are software-pipelined by one k-step: the dependent pair (v_accvgpr_read, v_max_i32) of step r+1 is
+    // split around the MFMAs of step r, so it costs two issue slots instead of two dependent-latency stalls + s_nop.
+    if constexpr (NT == 8) {
+        float b = RELU ? relu(in[0]) : in[0];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            f32x4 a0, a1;
+            if ((r & 7) == 4) pipe_sync(P);
+            pipe_advance(P, r & 7, a0, a1);
+            out[0] = MFMA(a0[0], b, out[0]); out[1] = MFMA(a0[1], b, out[1]);
+            pipe_mid_step(P, r & 7);
+            float raw = 0.f;
+            if (r < 15) { raw = in[r + 1]; asm volatile("" : "+v"(raw)); }
+            __builtin_amdgcn_sched_barrier(0);
+            out[2] = MFMA(a0[2], b, out[2]); out[3] = MFMA(a0[3], b, out[3]);
+            out[4] = MFMA(a1[0], b, out[4]);
+            __builtin_amdgcn_sched_barrier(0);
+            float bn = raw;
+            if (RELU) asm volatile("v_max_i32 %0, 0, %1" : "=v"(bn) : "v"(raw)); // consumer is >= 3 MFMAs away: no hazard
+            __builtin_amdgcn_sched_barrier(0);
+            out[5] = MFMA(a1[1], b, out[5]);
+            out[6] = MFMA(a1[2], b, out[6]); out[7] = MFMA(a1[3], b, out[7]);
+            b = bn;
+        }
+    } else {
+        float b0 = RELU ? relu(in[0]) : in[0];
+        float b1 = RELU ? relu(in[1]) : in[1];
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+            f32x4 a0, a1;
+            if (r / 2 == 4) pipe_sync(P);
+            pipe_advance(P, r / 2, a0, a1);
+            out[0] = MFMA(a0[0], b0, out[0]); out[1] = MFMA(a0[1], b0, out[1]);
+            pipe_mid_step(P, r / 2);
+            float r0 = 0.f, r1 = 0.f;
+            if (r < 14) { r0 = in[r + 2]; r1 = in[r + 3]; asm volatile("" : "+v"(r0), "+v"(r1)); }
+            __builtin_amdgcn_sched_barrier(0);
+            out[2] = MFMA(a0[2], b0, out[2]); out[3] = MFMA(a0[3], b0, out[3]);
+            out[0] = MFMA(a1[0], b1, out[0]);
+            __builtin_amdgcn_sched_barrier(0);
+            float n0 = r0, n1 = r1;
+            if (RELU) asm volatile("v_max_i32 %0, 0, %2\n\tv_max_i32 %1, 0, %3" : "=&v"(n0), "=v"(n1) : "v"(r0), "v"(r1));
+            __builtin_amdgcn_sched_barrier(0);
+            out[1] = MFMA(a1[1], b1, out[1]);
+            out[2] = MFMA(a1[2], b1, out[2]); out[3] = MFMA(a1[3], b1, out[3]);
+            b0 = n0; b1 = n1;
+        }
+    }
+#else
+    // Every interruption of the fp32 MFMA stream by VALU work costs more than the VALU instructions themselves, so
+    // the B operands of G consecutive k-steps are prepared in one burst (G more live VGPRs).
+    constexpr int G = RELU ? NERF_RELU_GROUP : 1;
+    float bq[G];
     if constexpr (NT == 8) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             f32x4 a0, a1;
             if ((r & 7) == 4) pipe_sync(P);
             pipe_advance(P, r & 7, a0, a1);
-            const float b = RELU ? relu(in[r]) : in[r];
+            if (r % G == 0) {
+#pragma unroll
+                for (int g = 0; g < G; ++g) bq[g] = RELU ? relu(in[r + g]) : in[r + g];
+                if (G > 1) __builtin_amdgcn_sched_barrier(0);
+            }
+            const float b = bq[r % G];
             out[0] = MFMA(a0[0], b, out[0]); out[1] = MFMA(a0[1], b, out[1]);
             pipe_mid_step(P, r & 7);
             out[2] = MFMA(a0[2], b, out[2]); out[3] = MFMA(a0[3], b, out[3]);
@@ -202,13 +279,19 @@ __device__ __forceinline__ void tile_steps(const f32x16 &in, f32x16 (&out)[NT], 
             out[6] = MFMA(a1[2], b, out[6]); out[7] = MFMA(a1[3], b, out[7]);
         }
     } else {
+        constexpr int G2 = G < 2 ? 2 : G;
+        float bq2[G2];
 #pragma unroll
         for (int r = 0; r < 16; r += 2) {
             f32x4 a0, a1;
             if (r / 2 == 4) pipe_sync(P);
             pipe_advance(P, r / 2, a0, a1);
-            const float b0 = RELU ? relu(in[r]) : in[r];
-            const float b1 = RELU ? relu(in[r + 1]) : in[r + 1];
+            if (r % G2 == 0) {
+#pragma unroll
+                for (int g = 0; g < G2; ++g) bq2[g] = RELU ? relu(in[r + g]) : in[r + g];
+                if (G2 > 2) __builtin_amdgcn_sched_barrier(0);
+            }
+            const float b0 = bq2[r % G2], b1 = bq2[r % G2 + 1];
             out[0] = MFMA(a0[0], b0, out[0]); out[1] = MFMA(a0[1], b0, out[1]);
             pipe_mid_step(P, r / 2);
             out[2] = MFMA(a0[2], b0, out[2]); out[3] = MFMA(a0[3], b0, out[3]);
@@ -216,6 +299,7 @@ __device__ __forceinline__ void tile_steps(const f32x16 &in, f32x16 (&out)[NT], 
             out[2] = MFMA(a1[2], b1, out[2]); out[3] = MFMA(a1[3], b1, out[3]);
         }
     }
+#endif
 }
 
 template <int NT>
@@ -324,8 +408,11 @@ __global__ __launch_bounds__(256, 1) void nerf_mlp_kernel(const MlpArgs A) {
     if (A.clock_out) { clk0 = __builtin_amdgcn_s_memtime(); rt0 = __builtin_amdgcn_s_memrealtime(); }
     P.rd_slot_off = 0;
     P.rd_base = P.ring_lane;
-    P.a0 = *(const LDS_AS f32x4 *)(P.rd_base); // prime: operands of macro-step 0
-    P.a1 = *(const LDS_AS f32x4 *)(P.rd_base + 1024);
+#pragma unroll
+    for (int j = 0; j < NERF_LDS_GROUP; ++j) { // prime: operands of the first group of macro-steps
+        P.nx[2 * j] = *(const LDS_AS f32x4 *)(P.rd_base + j * 2048);
+        P.nx[2 * j + 1] = *(const LDS_AS f32x4 *)(P.rd_base + j * 2048 + 1024);
+    }
 
     // Raw per-point inputs: 6 floats.  MODE_POINTS: position + direction as given (src/network.rs:197).
     // MODE_RAYS: (t, unused, unused) + the ray's unit direction; p = origin + dir_hat * t is formed at use with the
