@@ -90,6 +90,13 @@ int nerf_load_network_dir(nerf_ctx *ctx, int which, const char *dir);
 int nerf_load_network_tensors(nerf_ctx *ctx, int which, int n, const char *const *names, const int64_t *dims,
                               const float *const *data);
 
+/* Packed weight blob: the pre-padded, pre-permuted device image of one network in a single file, so
+ * that start-up is one read + one memcpy.  nerf_pack_network_dir converts the reference's directory format (host-only);
+ * nerf_load_network_blob uploads it.  The directory loader stays the compatibility path.  Blob layout: 16-byte header
+ * {"NRFMI355", u32 version = 1, u32 n_floats} + the weight stream + the small-parameter block (mlp_layout.h). */
+int nerf_pack_network_dir(const char *dir, const char *blob_path);
+int nerf_load_network_blob(nerf_ctx *ctx, int which, const char *blob_path);
+
 /* Host-only validation of a weight directory (same checks as nerf_load_network_dir, no device needed). */
 int nerf_check_network_dir(const char *dir);
 /* Diagnostic: the packed device images of a weight directory (layout: nerf-rs_amd/csrc/mlp_layout.h).  Pass NULL
@@ -127,6 +134,11 @@ int nerf_debug_shader_clock_mhz(nerf_ctx *ctx, double *mhz);
 int nerf_camera_from_json(const char *json_path, int width, int height, nerf_camera *out);
 int nerf_camera_from_values(float near_, float far_, const float origin[3], const float forward[3],
                             const float up[3], const float hwf[3], int width, int height, nerf_camera *out);
+/* Camera from a 3x4 camera-to-world pose (row-major; columns = right, up, -forward, origin -- the layout of
+ * "camera_matrix" in tf_reference_samples.json, which the reference reads but never uses).  focal in pixels of a
+ * ref_w x ref_h image (hwf); the result equals nerf_camera_from_values(origin, -col2, col1, ...). */
+int nerf_camera_from_pose(const float c2w[12], float ref_h, float ref_w, float focal, float near_, float far_, int width,
+                          int height, nerf_camera *out);
 /* save_ppm (src/lib.rs:567-580): P6, (clamp(v,0,1)*255+0.5) as u8 */
 int nerf_save_ppm(const char *path, int width, int height, const float *rgb);
 void nerf_quantize_rgb8(const float *rgb, size_t n_pixels, uint8_t *out);

@@ -47,6 +47,10 @@ PROTOTYPES = {
     "nerf_load_network_dir": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p]),
     "nerf_load_network_tensors": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_int64),
                                             C.POINTER(f32p)]),
+    "nerf_pack_network_dir": (C.c_int, [C.c_char_p, C.c_char_p]),
+    "nerf_load_network_blob": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p]),
+    "nerf_camera_from_pose": (C.c_int, [f32p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int,
+                                        C.POINTER(CCamera)]),
     "nerf_check_network_dir": (C.c_int, [C.c_char_p]),
     "nerf_debug_pack_network_dir": (C.c_int, [C.c_char_p, f32p, C.c_size_t, f32p, C.c_size_t, C.POINTER(C.c_size_t),
                                               C.POINTER(C.c_size_t)]),

@@ -148,6 +148,16 @@ def load_network_from_dir(renderer, which, directory):
     return Network(renderer, which)
 
 
+def pack_network_dir(directory, blob_path):
+    """Convert a reference-format weight directory into the packed one-memcpy blob (host-only)."""
+    check(_lib.load_library().nerf_pack_network_dir(str(directory).encode(), str(blob_path).encode()))
+
+
+def load_network_blob(renderer, which, blob_path):
+    check(renderer._L.nerf_load_network_blob(renderer.handle, which, str(blob_path).encode()), renderer.handle)
+    return Network(renderer, which)
+
+
 class Camera:
     """struct Camera (src/lib.rs:197-211)."""
 
@@ -179,6 +189,15 @@ def camera_from_samples(samples, width, height, coarse_samples_per_ray=64):
         except (KeyError, TypeError, ValueError) as e:
             raise NerfError(-7, f"camera JSON: missing or malformed key {e}")
         check(L.nerf_camera_from_values(near, far, _p(o), _p(fw), _p(up), _p(hwf), width, height, C.byref(c)))
+    return Camera(c, coarse_samples_per_ray)
+
+
+def camera_from_pose(c2w, hwf, near, far, width, height, coarse_samples_per_ray=64):
+    """Camera from a 3x4 camera-to-world matrix (the JSON's "camera_matrix") and hwf = (H, W, focal)."""
+    m = _f32(np.asarray(c2w)[:3, :4]).reshape(-1)
+    c = CCamera()
+    check(_lib.load_library().nerf_camera_from_pose(_p(m), float(hwf[0]), float(hwf[1]), float(hwf[2]), float(near), float(far),
+                                                  width, height, C.byref(c)))
     return Camera(c, coarse_samples_per_ray)
 
 

@@ -135,11 +135,17 @@ int ensure_workspace(nerf_ctx *c, size_t rays, size_t nc, size_t m) {
     return NERF_OK;
 }
 
+int upload_packed(nerf_ctx *c, int which, const std::vector<float> &ws, const std::vector<float> &sm);
+
 int upload_net(nerf_ctx *c, int which, const HostNet &hn) {
     std::vector<float> ws, sm;
     pack_network(hn, ws, sm);
-    if (ws.size() != (size_t)nerfmlp::kChunksFull * nerfmlp::kChunkFloats)
-        return fail(c, NERF_ERR_INVALID, "internal: packed stream size mismatch");
+    return upload_packed(c, which, ws, sm);
+}
+
+int upload_packed(nerf_ctx *c, int which, const std::vector<float> &ws, const std::vector<float> &sm) {
+    if (ws.size() != (size_t)nerfmlp::kChunksFull * nerfmlp::kChunkFloats || sm.size() != (size_t)nerfmlp::kSmallFloats)
+        return fail(c, NERF_ERR_SHAPE, "packed network image has the wrong size for this library build");
     DevNet &d = c->net[which];
     if (!d.wstream) HIP_TRY(c, hipMalloc((void **)&d.wstream, ws.size() * sizeof(float)));
     if (!d.small) HIP_TRY(c, hipMalloc((void **)&d.small, sm.size() * sizeof(float)));
@@ -412,6 +418,56 @@ int nerf_load_network_tensors(nerf_ctx *c, int which, int n, const char *const *
     const int rc = assemble_net(params, hn, err);
     if (rc) return fail(c, rc, err);
     return upload_net(c, which, hn);
+}
+
+static const char kBlobMagic[8] = {'N', 'R', 'F', 'M', 'I', '3', '5', '5'};
+
+int nerf_pack_network_dir(const char *dir, const char *blob_path) {
+    if (!dir || !blob_path) return fail(nullptr, NERF_ERR_INVALID, "NULL argument");
+    std::map<std::string, Tensor> params;
+    std::string err;
+    int rc = read_tensor_dir(dir, params, err);
+    if (rc) return fail(nullptr, rc, err);
+    HostNet hn;
+    rc = assemble_net(params, hn, err);
+    if (rc) return fail(nullptr, rc, err);
+    std::vector<float> ws, sm;
+    pack_network(hn, ws, sm);
+    FILE *f = fopen(blob_path, "wb");
+    if (!f) return fail(nullptr, NERF_ERR_IO, std::string("cannot create ") + blob_path);
+    const uint32_t hdr[2] = {1u, (uint32_t)(ws.size() + sm.size())};
+    const bool ok = fwrite(kBlobMagic, 1, 8, f) == 8 && fwrite(hdr, 4, 2, f) == 2 &&
+                    fwrite(ws.data(), 4, ws.size(), f) == ws.size() && fwrite(sm.data(), 4, sm.size(), f) == sm.size();
+    fclose(f);
+    return ok ? NERF_OK : fail(nullptr, NERF_ERR_IO, std::string("short write ") + blob_path);
+}
+
+int nerf_load_network_blob(nerf_ctx *c, int which, const char *blob_path) {
+    if (!c) return fail(nullptr, NERF_ERR_INVALID, "ctx is NULL");
+    if (which != NERF_NET_COARSE && which != NERF_NET_FINE) return fail(c, NERF_ERR_INVALID, "which must be NERF_NET_COARSE or NERF_NET_FINE");
+    if (!blob_path) return fail(c, NERF_ERR_INVALID, "blob_path is NULL");
+    DeviceGuard dg(c->device);
+    FILE *f = fopen(blob_path, "rb");
+    if (!f) return fail(c, NERF_ERR_IO, std::string("read blob: ") + blob_path);
+    char magic[8]; uint32_t hdr[2] = {0, 0};
+    const size_t nw = (size_t)nerfmlp::kChunksFull * nerfmlp::kChunkFloats, ns = nerfmlp::kSmallFloats;
+    std::vector<float> ws(nw), sm(ns);
+    const bool ok = fread(magic, 1, 8, f) == 8 && fread(hdr, 4, 2, f) == 2 && !memcmp(magic, kBlobMagic, 8) && hdr[0] == 1u &&
+                    hdr[1] == nw + ns && fread(ws.data(), 4, nw, f) == nw && fread(sm.data(), 4, ns, f) == ns && fgetc(f) == EOF;
+    fclose(f);
+    if (!ok) return fail(c, NERF_ERR_SHAPE, std::string("not a version-1 packed network blob for this build: ") + blob_path);
+    return upload_packed(c, which, ws, sm);
+}
+
+int nerf_camera_from_pose(const float c2w[12], float ref_h, float ref_w, float focal, float near_, float far_, int width,
+                          int height, nerf_camera *out) {
+    if (!c2w || !out) return fail(nullptr, NERF_ERR_INVALID, "NULL argument");
+    const float origin[3] = {c2w[3], c2w[7], c2w[11]};
+    const float forward[3] = {-c2w[2], -c2w[6], -c2w[10]};
+    const float up[3] = {c2w[1], c2w[5], c2w[9]};
+    const float hwf[3] = {ref_h, ref_w, focal};
+    camera_from_values(near_, far_, origin, forward, up, hwf, width, height, out);
+    return NERF_OK;
 }
 
 int nerf_check_network_dir(const char *dir) {

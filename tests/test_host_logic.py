@@ -240,3 +240,25 @@ def test_packed_layout_reproduces_the_network(native, oracle, samples, oracle_ne
     assert np.all(np.abs(rgb[:15] - exp_c) <= 1e-5)
     o_rgb, o_sig = oracle_nets[0 if which == "coarse" else 1].forward_batch(pts, dirs)
     assert np.all(np.abs(sigma - o_sig) <= 1e-4 * (1 + np.abs(o_sig))) and np.all(np.abs(rgb - o_rgb) <= 1e-5)
+
+
+def test_camera_from_pose_equals_camera_from_samples(native, samples):
+    """The JSON's camera_matrix (unused by the reference) gives the same camera as forward/up/origin."""
+    a = native.camera_from_samples(samples, 400, 400).c
+    b = native.camera_from_pose(samples["camera_matrix"], samples["hwf"], samples["near"], samples["far"], 400, 400).c
+    for f in ("alpha_width", "alpha_height", "near", "far"):
+        assert getattr(a, f) == getattr(b, f)
+    for f in ("pos", "dir", "up"):
+        assert np.allclose(list(getattr(a, f)), list(getattr(b, f)), atol=1e-7)
+
+
+def test_packed_blob_round_trip(native, tmp_path):
+    """nerf_pack_network_dir writes exactly the stream the directory loader would upload (host-only part)."""
+    blob = tmp_path / "coarse.nrf"
+    native.pack_network_dir(os.path.join(SCENE, "coarse"), blob)
+    raw = blob.read_bytes()
+    ws, sm = _pack(native, "coarse")
+    assert raw[:8] == b"NRFMI355" and np.frombuffer(raw[8:16], np.uint32).tolist() == [1, ws.size + sm.size]
+    assert np.array_equal(np.frombuffer(raw[16:], np.float32), np.concatenate([ws, sm]))
+    with pytest.raises(native.NerfError):
+        native.pack_network_dir(tmp_path / "missing", blob)
