@@ -19,6 +19,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # same table, "Peak BF16/FP16 MFMA ~2.5 PF dense"
 
 
 def pmc_traffic_bytes():
@@ -95,6 +96,9 @@ def main():
     ap.add_argument("--coarse", type=int, default=64)
     ap.add_argument("--fine", type=int, default=128)
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
+                    help="MLP arithmetic: f32 = BASELINE's headline config (C3, default); bf16 = the C5 study (not the headline)")
+    ap.add_argument("--ssaa", type=int, default=1, help="s x s rays per pixel (C5: --dtype bf16 --ssaa 2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-naive", action="store_true", help="also time the reference's own loop order (minutes)")
     args = ap.parse_args()
@@ -126,9 +130,11 @@ def main():
 
     def step():
         if not use_dist:
-            N.render_image(r.coarse, r.fine, cam, args.fine, seed=args.seed, device_out=frame.data_ptr(), stream=stream)
+            N.render_image(r.coarse, r.fine, cam, args.fine, seed=args.seed, ssaa=args.ssaa, dtype=args.dtype,
+                           device_out=frame.data_ptr(), stream=stream)
             return frame
-        return N.render_image_distributed(r.coarse, r.fine, cam, args.fine, seed=args.seed, return_tensor=True)
+        return N.render_image_distributed(r.coarse, r.fine, cam, args.fine, seed=args.seed, ssaa=args.ssaa, dtype=args.dtype,
+                                          return_tensor=True)
 
     def fence():
         if use_dist:
@@ -151,27 +157,31 @@ def main():
     dt = float(tmax.item())
 
     if rank == 0:
-        n_rays = args.width * args.height
+        n_rays = args.width * args.height * args.ssaa * args.ssaa
         flop_ray = N.flop_per_ray(args.coarse, args.fine)
+        bf16 = args.dtype == "bf16"
+        peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_FP32_MFMA_TFLOPS
         value = n_rays * args.steps / dt
         ach = pts_dom * N.FLOP_PER_POINT_FULL / (ms_dom * 1e-3) / 1e12 if ms_dom > 0 else 0.0
         line = {  # noqa: E501
             "metric": "rays/sec, lego 800x800 (64 coarse + 128 fine samples per ray)", "value": value, "unit": "rays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "bf16 operands / f32 accumulate (C5 study, PSNR-level parity)" if bf16 else "f32",
             "data": "real lego weights (lego_rust/, 2 x 595,844 f32 parameters) + tf_reference_samples.json camera; "
                     "sample positions from the seeded counter RNG (no dataset involved)",
-            "config": {"workload": f"C3: lego coarse+fine hierarchical, {args.width}x{args.height}, {args.coarse}+{args.fine} "
-                                   f"samples/ray, fp32, {world}xMI355X" + (", row bands + RCCL all-gather" if world > 1 else ""),
+            "config": {"workload": (f"C5-style: {args.ssaa}x{args.ssaa} SSAA, bf16 MLP, " if bf16 or args.ssaa > 1 else "C3: ") +
+                                   f"lego coarse+fine hierarchical, {args.width}x{args.height}, {args.coarse}+{args.fine} "
+                                   f"samples/ray, {args.dtype}, {world}xMI355X" + (", row bands + RCCL all-gather" if world > 1 else ""),
                        "rays_per_step": n_rays, "flop_per_ray": flop_ray, "seed": args.seed,
-                       "whole_job_fraction_of_fp32_mfma_roofline": value * flop_ray / (world * PEAK_FP32_MFMA_TFLOPS * 1e12)},
-            "roofline": {"bound": "mfma", "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": ach / PEAK_FP32_MFMA_TFLOPS, "traffic": pmc_traffic_bytes(),
-                         "kernel": "nerf_mlp_kernel<FULL=true, MODE_RAYS> (fine network)",
+                       "whole_job_fraction_of_mfma_roofline": value * flop_ray / (world * peak * 1e12)},
+            "roofline": {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
+                         "frac": ach / peak, "traffic": None if bf16 else pmc_traffic_bytes(),
+                         "kernel": ("nerf_mlp_kernel_bf16" if bf16 else "nerf_mlp_kernel") + "<FULL=true, MODE_RAYS> (fine network)",
                          "launches": n_dom, "avg_launch_ms": ms_dom / max(n_dom, 1),
                          "points_per_launch": pts_dom // max(n_dom, 1), "flop_per_point": N.FLOP_PER_POINT_FULL},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not bf16:
             line["cpu_baseline"] = cpu_baseline(args.width, args.height, args.coarse, args.fine, args.seed, args.cpu_naive)
         print(json.dumps(line), flush=True)
     del out

@@ -41,6 +41,7 @@ typedef enum {
 } nerf_status;
 
 enum { NERF_NET_COARSE = 0, NERF_NET_FINE = 1 };
+enum { NERF_MLP_F32 = 0, NERF_MLP_BF16 = 1 };
 
 /* Mirrors `struct Camera` (src/lib.rs:197-211); samples_per_ray lives in nerf_render_opts.n_coarse.
  * alpha_* are the half field-of-view angles (radians); dir/up need not be orthogonal (basis is rebuilt
@@ -61,7 +62,9 @@ typedef struct {
     int32_t crop_x0, crop_y0, crop_w, crop_h; /* ext: output window in pixels; crop_w = crop_h = 0 => full frame */
     int32_t ssaa;         /* ext: s x s rays per pixel, box filter; 0 or 1 => off */
     uint64_t seed;        /* counter-RNG seed (reference: unseeded thread_rng, src/lib.rs:375,407) */
-    int32_t reserved[4];  /* must be 0 */
+    int32_t mlp_dtype;    /* ext: NERF_MLP_F32 (0, default: exact-f32 MFMA, the parity path) or NERF_MLP_BF16 (1: bf16
+                           * operands / f32 accumulate on the bf16 matrix cores -- BASELINE config C5; PSNR-level parity) */
+    int32_t reserved[3];  /* must be 0 */
 } nerf_render_opts;
 
 /* Device-side timing of the last render (HIP events on the render stream). */
@@ -108,6 +111,9 @@ int nerf_debug_pack_network_dir(const char *dir, float *wstream, size_t wstream_
 /* host pointers, synchronous.  n == 0 is a no-op (src/network.rs:199-201). */
 int nerf_forward_batch(nerf_ctx *ctx, int which, const float *pts_soa /*3 x n*/, const float *dirs_aos /*n x 3*/,
                        size_t n, float *rgb_aos /*n x 3*/, float *sigma /*n*/);
+/* same with an explicit MLP arithmetic (NERF_MLP_F32 / NERF_MLP_BF16) */
+int nerf_forward_batch_ex(nerf_ctx *ctx, int which, int mlp_dtype, const float *pts_soa, const float *dirs_aos, size_t n,
+                          float *rgb_aos, float *sigma);
 /* device pointers, asynchronous on `stream` (a hipStream_t passed as void*; NULL = default stream) */
 int nerf_forward_batch_device(nerf_ctx *ctx, int which, const float *d_pts_soa, const float *d_dirs_aos, size_t n,
                               float *d_rgb_aos, float *d_sigma, void *stream);

@@ -28,7 +28,7 @@ class CCamera(C.Structure):
 class COpts(C.Structure):
     _fields_ = [("n_coarse", C.c_int32), ("n_fine", C.c_int32), ("coarse_only", C.c_int32),
                 ("crop_x0", C.c_int32), ("crop_y0", C.c_int32), ("crop_w", C.c_int32), ("crop_h", C.c_int32),
-                ("ssaa", C.c_int32), ("seed", C.c_uint64), ("reserved", C.c_int32 * 4)]
+                ("ssaa", C.c_int32), ("seed", C.c_uint64), ("mlp_dtype", C.c_int32), ("reserved", C.c_int32 * 3)]
 
 
 class CStats(C.Structure):
@@ -55,6 +55,7 @@ PROTOTYPES = {
     "nerf_debug_pack_network_dir": (C.c_int, [C.c_char_p, f32p, C.c_size_t, f32p, C.c_size_t, C.POINTER(C.c_size_t),
                                               C.POINTER(C.c_size_t)]),
     "nerf_forward_batch": (C.c_int, [C.c_void_p, C.c_int, f32p, f32p, C.c_size_t, f32p, f32p]),
+    "nerf_forward_batch_ex": (C.c_int, [C.c_void_p, C.c_int, C.c_int, f32p, f32p, C.c_size_t, f32p, f32p]),
     "nerf_forward_batch_device": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p,
                                             C.c_void_p, C.c_void_p]),
     "nerf_render_image": (C.c_int, [C.c_void_p, C.POINTER(CCamera), C.POINTER(COpts), f32p, C.POINTER(CStats)]),

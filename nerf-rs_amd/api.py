@@ -17,6 +17,8 @@ from . import _lib
 from ._lib import CCamera, COpts, CStats, NerfError, check, f32p, u32p
 
 NET_COARSE, NET_FINE = 0, 1
+MLP_F32, MLP_BF16 = 0, 1
+_DTYPES = {"f32": 0, "float32": 0, 0: 0, "bf16": 1, "bfloat16": 1, 1: 1}
 
 
 def _f32(a):
@@ -121,7 +123,7 @@ class Network:
         self.renderer = renderer
         self.which = which
 
-    def forward_batch(self, points, view_dirs):
+    def forward_batch(self, points, view_dirs, dtype="f32"):
         """points: (3, B) f32 SoA; view_dirs: (B, 3) -> (colours (B, 3), sigma (B,)).  B == 0 returns empties
         (src/network.rs:199-201)."""
         pts = _f32(points); dirs = _f32(view_dirs)
@@ -133,7 +135,7 @@ class Network:
         rgb = np.empty((n, 3), np.float32); sig = np.empty((n,), np.float32)
         if n:
             R = self.renderer
-            check(R._L.nerf_forward_batch(R.handle, self.which, _p(pts), _p(dirs), n, _p(rgb), _p(sig)), R.handle)
+            check(R._L.nerf_forward_batch_ex(R.handle, self.which, _DTYPES[dtype], _p(pts), _p(dirs), n, _p(rgb), _p(sig)), R.handle)
         return rgb, sig
 
     def forward_batch_device(self, d_points, d_view_dirs, d_rgb, d_sigma, n, stream=0):
@@ -202,16 +204,17 @@ def camera_from_pose(c2w, hwf, near, far, width, height, coarse_samples_per_ray=
 
 
 class RenderOpts:
-    def __init__(self, n_coarse=64, n_fine=128, coarse_only=False, crop=None, ssaa=1, seed=0):
+    def __init__(self, n_coarse=64, n_fine=128, coarse_only=False, crop=None, ssaa=1, seed=0, dtype="f32"):
         self.n_coarse, self.n_fine, self.coarse_only, self.crop, self.ssaa, self.seed = \
             n_coarse, n_fine, coarse_only, crop, ssaa, seed
+        self.dtype = _DTYPES[dtype]
 
     def to_c(self):
         o = COpts()
         o.n_coarse, o.n_fine, o.coarse_only = self.n_coarse, self.n_fine, int(self.coarse_only)
         if self.crop:
             o.crop_x0, o.crop_y0, o.crop_w, o.crop_h = self.crop
-        o.ssaa, o.seed = self.ssaa, self.seed
+        o.ssaa, o.seed, o.mlp_dtype = self.ssaa, self.seed, self.dtype
         return o
 
     def out_shape(self, cam):
@@ -219,7 +222,7 @@ class RenderOpts:
 
 
 def render_image(coarse, fine, camera, fine_samples_per_ray=128, *, seed=0, coarse_only=False, crop=None, ssaa=1,
-                 return_stats=False, device_out=None, stream=0):
+                 dtype="f32", return_stats=False, device_out=None, stream=0):
     """render_image (src/lib.rs:474-565) -> (h, w, 3) float32 linear RGB.
 
     coarse/fine: Network objects of one Renderer; camera.samples_per_ray is the coarse sample count.
@@ -228,7 +231,7 @@ def render_image(coarse, fine, camera, fine_samples_per_ray=128, *, seed=0, coar
     R = coarse.renderer
     if fine is not None and fine.renderer is not R:
         raise NerfError(-1, "coarse and fine networks must live in the same Renderer")
-    opts = RenderOpts(camera.samples_per_ray, fine_samples_per_ray, coarse_only, crop, ssaa, seed)
+    opts = RenderOpts(camera.samples_per_ray, fine_samples_per_ray, coarse_only, crop, ssaa, seed, dtype)
     o = opts.to_c()
     st = CStats()
     if device_out is not None:

@@ -156,6 +156,48 @@ void pack_network(const HostNet &net, std::vector<float> &ws, std::vector<float>
     for (int c = 0; c < 3; ++c) sm[kMiscOff + 1 + c] = net.rgb.b[c];
 }
 
+// ---- bf16 stream -------------------------------------------------------------------------------
+uint16_t f32_to_bf16_rne(float v) {
+    uint32_t u;
+    memcpy(&u, &v, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40u); // NaN stays NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+
+// rowfn(tile, r, h): weight row held by register r (0..15) of input tile `tile` on lane-half h, or -1.
+template <class RowFn>
+static void pack_layer_bf16(std::vector<uint16_t> &s, const HostNet::L &L, int n_tiles, int NT, RowFn row) {
+    for (int tt = 0; tt < n_tiles; ++tt)
+        for (int ks = 0; ks < 2; ++ks)
+            for (int nt = 0; nt < NT; ++nt)
+                for (int l = 0; l < 64; ++l)
+                    for (int j = 0; j < 8; ++j) { // B-fragment element j of k-step ks = register 8 ks + j of the tile
+                        const int r = row(tt, 8 * ks + j, l >> 5);
+                        const int n = 32 * nt + (l & 31);
+                        s.push_back((r >= 0 && r < L.K && n < L.N) ? f32_to_bf16_rne(L.w[(size_t)r * L.N + n]) : (uint16_t)0);
+                    }
+}
+
+void pack_network_bf16(const HostNet &net, std::vector<uint16_t> &ws) {
+    ws.clear();
+    ws.reserve((size_t)kChunksFullBf16 * kChunkBytesBf16 / 2);
+    auto hid = [](int tt, int r, int h) { return 32 * tt + regFeature(r, h); };
+    pack_layer_bf16(ws, net.dense[0], 2, 8, [](int tt, int r, int h) { return posSlotFeature(16 * tt + r, h); });
+    for (int i = 1; i < 5; ++i) pack_layer_bf16(ws, net.dense[i], 8, 8, hid);
+    pack_layer_bf16(ws, net.dense[5], 10, 8, [](int tt, int r, int h) {
+        return tt < 2 ? posSlotFeature(16 * tt + r, h) : 63 + 32 * (tt - 2) + regFeature(r, h);
+    });
+    for (int i = 6; i < 8; ++i) pack_layer_bf16(ws, net.dense[i], 8, 8, hid);
+    pack_layer_bf16(ws, net.bottleneck, 8, 8, hid);
+    pack_layer_bf16(ws, net.viewdirs, 9, 4, [](int tt, int r, int h) {
+        if (tt < 8) return 32 * tt + regFeature(r, h);
+        const int f = dirSlotFeature(r, h);
+        return f < 0 ? -1 : 256 + f;
+    });
+    ws.resize((size_t)kChunksFullBf16 * kChunkBytesBf16 / 2, (uint16_t)0); // pad viewdirs to whole chunks
+}
+
 // ------------------------------------------------------------------------------------------------
 // Camera (reference src/lib.rs:614-645, 213-231; src/vec3.rs:19-34)
 // ------------------------------------------------------------------------------------------------

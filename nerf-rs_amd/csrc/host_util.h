@@ -32,6 +32,9 @@ int assemble_net(std::map<std::string, Tensor> &params, HostNet &net, std::strin
 
 // Packed device images (mlp_layout.h).
 void pack_network(const HostNet &net, std::vector<float> &wstream, std::vector<float> &small);
+// bf16 weight stream of mlp_kernel_bf16.hip (round-to-nearest-even); the small-parameter block is shared with fp32.
+void pack_network_bf16(const HostNet &net, std::vector<uint16_t> &wstream);
+uint16_t f32_to_bf16_rne(float v);
 
 // camera_from_samples (src/lib.rs:614-645)
 void camera_from_values(float near_, float far_, const float origin[3], const float forward[3], const float up[3],

@@ -27,3 +27,6 @@ struct MlpArgs {
 hipError_t nerf_mlp_init();
 // full=false evaluates dense0..7 + alpha only (sigma); n_blocks = persistent workgroups (<= #CUs).
 hipError_t nerf_mlp_launch(const MlpArgs &a, bool full, int n_blocks, hipStream_t stream);
+// bf16-operand variant (mlp_kernel_bf16.hip): a.wstream is the bf16 stream of pack_network_bf16
+hipError_t nerf_mlp_bf16_init();
+hipError_t nerf_mlp_bf16_launch(const MlpArgs &a, bool full, int n_blocks, hipStream_t stream);

@@ -1,0 +1,421 @@
+// mlp_kernel_bf16.hip -- the fused NeRF MLP with bf16 operands on v_mfma_f32_32x32x16_bf16 (fp32 accumulate).
+//
+// BASELINE.json config C5 ("bf16 MLP on CDNA4 MFMA ... bandwidth/compute roofline study").  Same structure as the fp32
+// kernel (mlp_kernel.hip): one persistent 256-thread workgroup per CU, a wave owns 32 points, activations stay in
+// registers as fp32 accumulators in the 32x32 C/D layout.  A finished accumulator tile becomes the next layer's B
+// operand without leaving registers: registers 8s..8s+7 of a tile, ReLU'd and converted pairwise with
+// v_cvt_pk_bf16_f32, are the 8-element B fragment of k-step s (K = 16) -- element j of lane-half h is feature
+// 16 s + 8 (j >> 2) + 4 h + (j & 3) of the tile, and the host packs the weight rows in exactly that order
+// (host_util.cpp::pack_network_bf16).  Encodings, biases, accumulation, the alpha / rgb heads and the sigmoid stay fp32.
+//
+// What changes against fp32: the MFMA rate is 16x, so per 32-point tile the matrix work is 1160 MFMAs x 32 cycles =
+// 37 k cycles while the whole bf16 network (1.16 MiB) still has to stream L2 -> LDS once per tile and per CU:
+// 32 B/clk/CU.  The kernel is therefore bound by the weight stream (LDS-DMA issue + L2 bandwidth), not by the matrix
+// pipe -- which is what the study is meant to show.
+//
+// Stream geometry: macro-step = 8 KiB = the A operands of 8 MFMAs (one K=16 step of an 8-tile layer, or two steps of
+// the 4-tile viewdirs layer); 32-KiB chunks (4 macro-steps) in a 3-slot ring; one vmcnt(0)+s_barrier per chunk at
+// macro-step 2; every macro-step issues 2 of the 8 LDS-DMA pieces this wave contributes to the chunk after next.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "mlp_kernel.h"
+#include "mlp_layout.h"
+
+using namespace nerfmlp;
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+#define LDS_AS __attribute__((address_space(3)))
+
+namespace {
+
+constexpr int kCB = kChunkBytesBf16;   // 32 KiB
+constexpr int kRS = kRingSlotsBf16;    // 3
+constexpr int kMS = 8192;              // bytes per macro-step
+
+struct PipeB {
+    const LDS_AS char *rd_base;   // LDS address (incl. lane*16) of the chunk the next macro-step to fetch lives in
+    const LDS_AS char *ring_lane; // ring base + lane*16
+    uint32_t rd_slot_off;
+    bf16x8 nx[8];                 // prefetched A operands of the next macro-step
+    uint32_t ring_addr;           // LDS byte address of the ring + wave*8 KiB (DMA destination base)
+    uint32_t wr_slot_off, next_off, stream_bytes;
+    const char *gbase;            // stream + wave*8 KiB
+    const char *cur_src;
+    uint32_t cur_dst;
+    uint32_t lane16;
+};
+
+__device__ __forceinline__ void glds_piece(uint32_t lane16, const char *gsrc, uint32_t dst) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\t"
+                 "s_mov_b32 m0, %3\n\t"
+                 "s_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, %2\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(lane16), "s"(gsrc), "s"(dst)
+                 : "memory");
+}
+
+__device__ __forceinline__ void pipe_next_chunk(PipeB &P) {
+    uint32_t off = P.next_off, slot = P.wr_slot_off;
+    asm volatile("" : "+s"(off), "+s"(slot));
+    P.cur_src = P.gbase + off;
+    P.cur_dst = P.ring_addr + slot;
+    off += kCB;
+    P.next_off = (off == P.stream_bytes) ? 0u : off;
+    slot += kCB;
+    P.wr_slot_off = (slot == kRS * kCB) ? 0u : slot;
+}
+
+// this wave's 8 KiB of the chunk = 8 pieces; piece i
+__device__ __forceinline__ void pipe_issue_piece(PipeB &P, int i) { glds_piece(P.lane16, P.cur_src + i * 1024, P.cur_dst + i * 1024); }
+
+// Macro-step `ms` (0..3 within its chunk) begins: at ms == 2 the chunk after this one must have landed and the slot of
+// the previous chunk may be refilled; then fetch the A operands of the NEXT macro-step.
+__device__ __forceinline__ void pipe_begin(PipeB &P, int ms, bf16x8 (&a)[8]) {
+    if (ms == 2) {
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        pipe_next_chunk(P);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a[j] = P.nx[j];
+    int nxt = ms + 1;
+    if (nxt == 4) {
+        uint32_t off = P.rd_slot_off + kCB;
+        off = (off == kRS * kCB) ? 0u : off;
+        P.rd_slot_off = off;
+        P.rd_base = P.ring_lane + off;
+        nxt = 0;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) P.nx[j] = *(const LDS_AS bf16x8 *)(P.rd_base + nxt * kMS + j * 1024);
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// The two DMA pieces of macro-step ms: pieces of the chunk selected at the last sync, in issue order
+// ms 2 -> 0,1   ms 3 -> 2,3   ms 0 -> 4,5   ms 1 -> 6,7.
+__device__ __forceinline__ void pipe_dma(PipeB &P, int ms, int k) {
+    const int base = ((ms + 2) & 3) * 2;
+    __builtin_amdgcn_sched_barrier(0);
+    pipe_issue_piece(P, base + k);
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+__device__ __forceinline__ float relu(float v) {
+    const int b = __builtin_bit_cast(int, v);
+    return __builtin_bit_cast(float, b > 0 ? b : 0);
+}
+
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
+
+// B fragment of k-step s: registers 8s .. 8s+7 of the tile -> 8 bf16 (element j = register 8s + j).
+template <bool RELU>
+__device__ __forceinline__ bf16x8 make_b(const f32x16 &in, int s) {
+    bf16x8 b;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        float x = in[8 * s + 2 * q], y = in[8 * s + 2 * q + 1];
+        if (RELU) { x = relu(x); y = relu(y); }
+        const f32x2 p = {x, y};
+        const bf16x2 c = __builtin_convertvector(p, bf16x2);
+        b[2 * q] = c[0];
+        b[2 * q + 1] = c[1];
+    }
+    return b;
+}
+
+// One input tile (32 features) of a layer with NT output tiles.  MS0 = macro-step (within its chunk) the tile starts at.
+template <int NT, bool RELU, int MS0>
+__device__ __forceinline__ void tile_steps(const f32x16 &in, f32x16 (&out)[NT], PipeB &P) {
+    const bf16x8 b0 = make_b<RELU>(in, 0), b1 = make_b<RELU>(in, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    bf16x8 a[8];
+    if constexpr (NT == 8) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const bf16x8 b = s ? b1 : b0;
+            pipe_begin(P, MS0 + s, a);
+            out[0] = MFMA16(a[0], b, out[0]); out[1] = MFMA16(a[1], b, out[1]);
+            pipe_dma(P, MS0 + s, 0);
+            out[2] = MFMA16(a[2], b, out[2]); out[3] = MFMA16(a[3], b, out[3]);
+            out[4] = MFMA16(a[4], b, out[4]); out[5] = MFMA16(a[5], b, out[5]);
+            pipe_dma(P, MS0 + s, 1);
+            out[6] = MFMA16(a[6], b, out[6]); out[7] = MFMA16(a[7], b, out[7]);
+        }
+    } else {
+        pipe_begin(P, MS0, a);
+        out[0] = MFMA16(a[0], b0, out[0]); out[1] = MFMA16(a[1], b0, out[1]);
+        pipe_dma(P, MS0, 0);
+        out[2] = MFMA16(a[2], b0, out[2]); out[3] = MFMA16(a[3], b0, out[3]);
+        out[0] = MFMA16(a[4], b1, out[0]); out[1] = MFMA16(a[5], b1, out[1]);
+        pipe_dma(P, MS0, 1);
+        out[2] = MFMA16(a[6], b1, out[2]); out[3] = MFMA16(a[7], b1, out[3]);
+    }
+}
+
+// A macro-step of stream padding: keep the pipeline bookkeeping (sync, prefetch, DMA), no matrix work.
+template <int MS>
+__device__ __forceinline__ void skip_macro_step(PipeB &P) {
+    bf16x8 a[8];
+    pipe_begin(P, MS, a);
+    pipe_dma(P, MS, 0);
+    pipe_dma(P, MS, 1);
+}
+
+template <int NT>
+__device__ __forceinline__ void load_bias(f32x16 (&out)[NT], const LDS_AS float *bias, int h) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const LDS_AS f32x4 *b = (const LDS_AS f32x4 *)(bias + (nt * 2 + h) * 16);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 v = b[q];
+            out[nt][4 * q + 0] = v[0]; out[nt][4 * q + 1] = v[1]; out[nt][4 * q + 2] = v[2]; out[nt][4 * q + 3] = v[3];
+        }
+    }
+}
+
+template <bool RELU>
+__device__ __forceinline__ void hidden_layer(const f32x16 (&in)[8], f32x16 (&out)[8], const LDS_AS float *bias, PipeB &P, int h) {
+    load_bias<8>(out, bias, h);
+    tile_steps<8, RELU, 0>(in[0], out, P); tile_steps<8, RELU, 2>(in[1], out, P);
+    tile_steps<8, RELU, 0>(in[2], out, P); tile_steps<8, RELU, 2>(in[3], out, P);
+    tile_steps<8, RELU, 0>(in[4], out, P); tile_steps<8, RELU, 2>(in[5], out, P);
+    tile_steps<8, RELU, 0>(in[6], out, P); tile_steps<8, RELU, 2>(in[7], out, P);
+}
+
+__device__ __forceinline__ void fast_sincos(float x, float *s_out, float *c_out) { // see mlp_kernel.hip
+    const float k = __builtin_rintf(x * 0.636619772f);
+    float r = fmaf(k, -1.5707963705062866f, x);
+    r = fmaf(k, 4.371138828673793e-08f, r);
+    r = fmaf(k, 1.7763568394002505e-15f, r);
+    const float r2 = r * r;
+    float ps = fmaf(r2, -1.9515295891e-4f, 8.3321608736e-3f);
+    ps = fmaf(r2, ps, -1.6666654611e-1f);
+    const float s = fmaf(r * r2, ps, r);
+    float pc = fmaf(r2, 2.443315711809948e-5f, -1.388731625493765e-3f);
+    pc = fmaf(r2, pc, 4.166664568298827e-2f);
+    const float c = fmaf(r2 * r2, pc, fmaf(r2, -0.5f, 1.0f));
+    const uint32_t q = (uint32_t)(int)k;
+    const bool swap = (q & 1u) != 0;
+    const uint32_t sb = __builtin_bit_cast(uint32_t, swap ? c : s) ^ ((q & 2u) << 30);
+    const uint32_t cb = __builtin_bit_cast(uint32_t, swap ? s : c) ^ (((q + 1u) & 2u) << 30);
+    *s_out = __builtin_bit_cast(float, sb);
+    *c_out = __builtin_bit_cast(float, cb);
+}
+
+__device__ __forceinline__ float xhalf_sum(float v) { return v + __shfl_xor(v, 32, 64); }
+
+__device__ __forceinline__ float alpha_head(const f32x16 (&Y)[8], const LDS_AS float *small, int h) {
+    const LDS_AS f32x4 *w = (const LDS_AS f32x4 *)(small + kAlphaWOff + h * 128);
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 wv = w[t * 4 + q];
+            a0 = fmaf(wv[0], relu(Y[t][4 * q + 0]), a0);
+            a1 = fmaf(wv[1], relu(Y[t][4 * q + 1]), a1);
+            a2 = fmaf(wv[2], relu(Y[t][4 * q + 2]), a2);
+            a3 = fmaf(wv[3], relu(Y[t][4 * q + 3]), a3);
+        }
+    }
+    return fmaxf(xhalf_sum((a0 + a1) + (a2 + a3)) + small[kMiscOff + 0], 0.f);
+}
+
+} // namespace
+
+template <bool FULL, int MODE>
+__global__ __launch_bounds__(256, 1) void nerf_mlp_kernel_bf16(const MlpArgs A) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const LDS_AS char *lds = (const LDS_AS char *)smem;
+    const LDS_AS float *small = (const LDS_AS float *)(lds + kRS * kCB);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int p = lane & 31;
+    const int h = lane >> 5;
+    const int lane16 = lane * 16;
+
+    {
+        float *dst = (float *)(smem + kRS * kCB);
+        for (int i = tid; i < kSmallFloats; i += 256) dst[i] = A.small_params[i];
+    }
+
+    PipeB P;
+    P.lane16 = lane16;
+    P.ring_lane = lds + lane16;
+    P.ring_addr = (uint32_t)(uintptr_t)lds + wave * 8192;
+    P.wr_slot_off = 0;
+    P.next_off = 0;
+    P.stream_bytes = (FULL ? kChunksFullBf16 : kChunksSigmaBf16) * kCB;
+    P.gbase = (const char *)A.wstream + wave * 8192;
+    __syncthreads();
+    // prologue = the state a steady-state pipeline is in when chunk 0 starts: chunk 0 landed; chunk 1 selected with the
+    // four pieces macro-steps 2,3 of "chunk -1" would have issued (macro-steps 0,1 of chunk 0 issue its pieces 4..7).
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        pipe_next_chunk(P);
+#pragma unroll
+        for (int i = 0; i < (c < 1 ? 8 : 4); ++i) pipe_issue_piece(P, i);
+    }
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    P.rd_slot_off = 0;
+    P.rd_base = P.ring_lane;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) P.nx[j] = *(const LDS_AS bf16x8 *)(P.rd_base + j * 1024);
+
+    struct RawIn { float a, b, c, dx, dy, dz; };
+    auto load_raw = [&](int tile_idx) -> RawIn {
+        RawIn r;
+        int i = tile_idx * kPointsPerBlock + wave * kPointsPerWave + p;
+        i = i < A.n_points ? i : A.n_points - 1;
+        if (MODE == MLP_MODE_POINTS) {
+            r.a = A.pts_soa[i]; r.b = A.pts_soa[(size_t)A.n_points + i]; r.c = A.pts_soa[2 * (size_t)A.n_points + i];
+            r.dx = A.dirs_aos[3 * (size_t)i]; r.dy = A.dirs_aos[3 * (size_t)i + 1]; r.dz = A.dirs_aos[3 * (size_t)i + 2];
+        } else {
+            const int ray = i / A.samples_per_ray;
+            r.a = A.t[i]; r.b = 0.f; r.c = 0.f;
+            r.dx = A.ray_dirs[3 * (size_t)ray]; r.dy = A.ray_dirs[3 * (size_t)ray + 1]; r.dz = A.ray_dirs[3 * (size_t)ray + 2];
+        }
+        return r;
+    };
+
+    const int n_tiles = (A.n_points + kPointsPerBlock - 1) / kPointsPerBlock;
+    RawIn nxt = load_raw(blockIdx.x);
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int i = tile * kPointsPerBlock + wave * kPointsPerWave + p;
+        const bool valid = i < A.n_points;
+        const RawIn in = nxt;
+        nxt = load_raw(tile + gridDim.x);
+        float px, py, pz;
+        const float dx = in.dx, dy = in.dy, dz = in.dz;
+        if (MODE == MLP_MODE_POINTS) {
+            px = in.a; py = in.b; pz = in.c;
+        } else {
+            px = __fadd_rn(A.origin[0], __fmul_rn(dx, in.a));
+            py = __fadd_rn(A.origin[1], __fmul_rn(dy, in.a));
+            pz = __fadd_rn(A.origin[2], __fmul_rn(dz, in.a));
+        }
+
+        f32x16 E[2];
+        {
+            float f = h ? 32.0f : 1.0f;
+#pragma unroll
+            for (int o = 0; o < 5; ++o) {
+                float s, c;
+                fast_sincos(f * px, &s, &c); E[(6 * o + 0) >> 4][(6 * o + 0) & 15] = s; E[(6 * o + 3) >> 4][(6 * o + 3) & 15] = c;
+                fast_sincos(f * py, &s, &c); E[(6 * o + 1) >> 4][(6 * o + 1) & 15] = s; E[(6 * o + 4) >> 4][(6 * o + 4) & 15] = c;
+                fast_sincos(f * pz, &s, &c); E[(6 * o + 2) >> 4][(6 * o + 2) & 15] = s; E[(6 * o + 5) >> 4][(6 * o + 5) & 15] = c;
+                f *= 2.0f;
+            }
+            E[1][14] = h ? pz : px;
+            E[1][15] = h ? 0.0f : py;
+        }
+
+        f32x16 X[8], Y[8];
+        load_bias<8>(X, small + kBiasOff + 0 * 256, h);
+        tile_steps<8, false, 0>(E[0], X, P);
+        tile_steps<8, false, 2>(E[1], X, P);
+        hidden_layer<true>(X, Y, small + kBiasOff + 1 * 256, P, h);
+        hidden_layer<true>(Y, X, small + kBiasOff + 2 * 256, P, h);
+        hidden_layer<true>(X, Y, small + kBiasOff + 3 * 256, P, h);
+        hidden_layer<true>(Y, X, small + kBiasOff + 4 * 256, P, h);
+        load_bias<8>(Y, small + kBiasOff + 5 * 256, h);
+        tile_steps<8, false, 0>(E[0], Y, P);
+        tile_steps<8, false, 2>(E[1], Y, P);
+        tile_steps<8, true, 0>(X[0], Y, P); tile_steps<8, true, 2>(X[1], Y, P);
+        tile_steps<8, true, 0>(X[2], Y, P); tile_steps<8, true, 2>(X[3], Y, P);
+        tile_steps<8, true, 0>(X[4], Y, P); tile_steps<8, true, 2>(X[5], Y, P);
+        tile_steps<8, true, 0>(X[6], Y, P); tile_steps<8, true, 2>(X[7], Y, P);
+        hidden_layer<true>(Y, X, small + kBiasOff + 6 * 256, P, h);
+        hidden_layer<true>(X, Y, small + kBiasOff + 7 * 256, P, h);
+
+        const float sigma = alpha_head(Y, small, h);
+        if (valid && h == 0) A.sigma_out[i] = sigma;
+
+        if (FULL) {
+            hidden_layer<true>(Y, X, small + kBiasOff + 8 * 256, P, h); // bottleneck, no activation on its output
+            f32x16 D;
+            {
+                float f = h ? 4.0f : 1.0f;
+#pragma unroll
+                for (int o = 0; o < 2; ++o) {
+                    float s, c;
+                    fast_sincos(f * dx, &s, &c); D[6 * o + 0] = s; D[6 * o + 3] = c;
+                    fast_sincos(f * dy, &s, &c); D[6 * o + 1] = s; D[6 * o + 4] = c;
+                    fast_sincos(f * dz, &s, &c); D[6 * o + 2] = s; D[6 * o + 5] = c;
+                    f *= 2.0f;
+                }
+                D[12] = h ? 0.f : dx; D[13] = h ? 0.f : dy; D[14] = h ? 0.f : dz; D[15] = 0.f;
+            }
+            f32x16 V[4];
+            load_bias<4>(V, small + kBiasViewOff, h);
+            tile_steps<4, false, 0>(X[0], V, P); tile_steps<4, false, 1>(X[1], V, P);
+            tile_steps<4, false, 2>(X[2], V, P); tile_steps<4, false, 3>(X[3], V, P);
+            tile_steps<4, false, 0>(X[4], V, P); tile_steps<4, false, 1>(X[5], V, P);
+            tile_steps<4, false, 2>(X[6], V, P); tile_steps<4, false, 3>(X[7], V, P);
+            tile_steps<4, false, 0>(D, V, P);
+            skip_macro_step<1>(P); skip_macro_step<2>(P); skip_macro_step<3>(P); // stream padding to the chunk end
+            float c[3];
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) {
+                const LDS_AS f32x4 *w = (const LDS_AS f32x4 *)(small + kRgbWOff + (h * 3 + ch) * 64);
+                float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const f32x4 wv = w[t * 4 + q];
+                        a0 = fmaf(wv[0], relu(V[t][4 * q + 0]), a0);
+                        a1 = fmaf(wv[1], relu(V[t][4 * q + 1]), a1);
+                        a2 = fmaf(wv[2], relu(V[t][4 * q + 2]), a2);
+                        a3 = fmaf(wv[3], relu(V[t][4 * q + 3]), a3);
+                    }
+                }
+                const float v = xhalf_sum((a0 + a1) + (a2 + a3)) + small[kMiscOff + 1 + ch];
+                c[ch] = 1.0f / (1.0f + expf(-v));
+            }
+            if (valid && h == 0) {
+                A.rgb_out[3 * (size_t)i + 0] = c[0];
+                A.rgb_out[3 * (size_t)i + 1] = c[1];
+                A.rgb_out[3 * (size_t)i + 2] = c[2];
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+template <bool FULL, int MODE>
+static hipError_t launch_t(const MlpArgs &a, int n_blocks, hipStream_t stream) {
+    hipLaunchKernelGGL((nerf_mlp_kernel_bf16<FULL, MODE>), dim3(n_blocks), dim3(256), kLdsBytesBf16, stream, a);
+    return hipGetLastError();
+}
+
+hipError_t nerf_mlp_bf16_init() {
+    const void *ks[4] = {(const void *)nerf_mlp_kernel_bf16<true, MLP_MODE_POINTS>, (const void *)nerf_mlp_kernel_bf16<false, MLP_MODE_POINTS>,
+                         (const void *)nerf_mlp_kernel_bf16<true, MLP_MODE_RAYS>, (const void *)nerf_mlp_kernel_bf16<false, MLP_MODE_RAYS>};
+    for (int i = 0; i < 4; ++i) {
+        hipError_t e = hipFuncSetAttribute(ks[i], hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytesBf16);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
+hipError_t nerf_mlp_bf16_launch(const MlpArgs &a, bool full, int n_blocks, hipStream_t stream) {
+    if (a.n_points <= 0) return hipSuccess;
+    const int n_tiles = (a.n_points + kPointsPerBlock - 1) / kPointsPerBlock;
+    if (n_blocks > n_tiles) n_blocks = n_tiles;
+    if (n_blocks < 1) n_blocks = 1;
+    if (a.mode == MLP_MODE_POINTS)
+        return full ? launch_t<true, MLP_MODE_POINTS>(a, n_blocks, stream) : launch_t<false, MLP_MODE_POINTS>(a, n_blocks, stream);
+    return full ? launch_t<true, MLP_MODE_RAYS>(a, n_blocks, stream) : launch_t<false, MLP_MODE_RAYS>(a, n_blocks, stream);
+}

@@ -51,6 +51,15 @@ constexpr int kSmallBytes = kSmallFloats * 4;
 
 constexpr int kLdsBytes = kRingSlots * kChunkBytes + kSmallBytes;
 
+// ---- bf16 stream (mlp_kernel_bf16.hip): macro-step = 8 KiB (8 pieces of 64 lanes x 8 bf16), 32-KiB chunks.
+// Per input tile (32 k-rows) an 8-tile layer has 2 k-steps x 8 pieces = 2 macro-steps; the 4-tile viewdirs layer
+// 2 k-steps x 4 pieces = 1 macro-step.  viewdirs (9 tiles = 72 KiB) is zero-padded to 3 chunks.
+constexpr int kChunkBytesBf16 = 32768;
+constexpr int kRingSlotsBf16 = 3;
+constexpr int kChunksSigmaBf16 = 1 + 4 * 4 + 5 + 2 * 4;        // dense0 (2 tiles), dense1-4, dense5 (10 tiles), dense6-7 = 30
+constexpr int kChunksFullBf16 = kChunksSigmaBf16 + 4 + 3;       // + bottleneck + viewdirs (padded) = 37
+constexpr int kLdsBytesBf16 = kRingSlotsBf16 * kChunkBytesBf16 + kSmallBytes;
+
 // feature held by register r (0..15) of a tile on lane-half h, relative to the tile's first feature
 constexpr int regFeature(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 

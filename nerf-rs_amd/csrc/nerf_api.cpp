@@ -29,6 +29,7 @@ thread_local std::string g_err; // context-free calls
 
 struct DevNet {
     float *wstream = nullptr, *small = nullptr;
+    uint16_t *wstream_bf16 = nullptr; // built from the same tensors at load time (mlp_kernel_bf16.hip)
     bool loaded = false;
 };
 
@@ -137,10 +138,49 @@ int ensure_workspace(nerf_ctx *c, size_t rays, size_t nc, size_t m) {
 
 int upload_packed(nerf_ctx *c, int which, const std::vector<float> &ws, const std::vector<float> &sm);
 
+int upload_bf16(nerf_ctx *c, int which, const std::vector<uint16_t> &wb) {
+    DevNet &d = c->net[which];
+    if (!d.wstream_bf16) HIP_TRY(c, hipMalloc((void **)&d.wstream_bf16, wb.size() * sizeof(uint16_t)));
+    HIP_TRY(c, hipMemcpy(d.wstream_bf16, wb.data(), wb.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    return NERF_OK;
+}
+
 int upload_net(nerf_ctx *c, int which, const HostNet &hn) {
     std::vector<float> ws, sm;
     pack_network(hn, ws, sm);
-    return upload_packed(c, which, ws, sm);
+    int rc = upload_packed(c, which, ws, sm);
+    if (rc) return rc;
+    std::vector<uint16_t> wb;
+    pack_network_bf16(hn, wb);
+    return upload_bf16(c, which, wb);
+}
+
+// The bf16 stream holds the same weights in another order; for networks that arrive as a packed f32 blob it is
+// rebuilt from the f32 stream's pieces (piece (s, g): lane l, q -> W[row(s, l >> 5)][32 (4 g + q) + (l & 31)]).
+int bf16_from_f32_stream(nerf_ctx *c, int which, const std::vector<float> &ws) {
+    using namespace nerfmlp;
+    std::vector<uint16_t> wb;
+    wb.reserve((size_t)kChunksFullBf16 * kChunkBytesBf16 / 2);
+    size_t layer_base = 0; // floats
+    auto layer = [&](int n_tiles, int NT) {
+        for (int tt = 0; tt < n_tiles; ++tt)
+            for (int ks = 0; ks < 2; ++ks)
+                for (int nt = 0; nt < NT; ++nt)
+                    for (int l = 0; l < 64; ++l)
+                        for (int j = 0; j < 8; ++j) {
+                            const int st = 16 * tt + 8 * ks + j; // f32 k-step that holds register 8 ks + j of tile tt
+                            const size_t piece = layer_base + ((size_t)st * (NT / 4) + nt / 4) * 256;
+                            wb.push_back(f32_to_bf16_rne(ws[piece + (size_t)l * 4 + (nt & 3)]));
+                        }
+        layer_base += (size_t)n_tiles * 16 * NT * 64;
+    };
+    layer(2, 8);
+    for (int i = 0; i < 4; ++i) layer(8, 8);
+    layer(10, 8);
+    for (int i = 0; i < 3; ++i) layer(8, 8);
+    layer(9, 4);
+    wb.resize((size_t)kChunksFullBf16 * kChunkBytesBf16 / 2, (uint16_t)0);
+    return upload_bf16(c, which, wb);
 }
 
 int upload_packed(nerf_ctx *c, int which, const std::vector<float> &ws, const std::vector<float> &sm) {
@@ -188,6 +228,8 @@ int render_device(nerf_ctx *c, const nerf_camera *cam, const nerf_render_opts *o
     if (o->n_coarse <= 0) return fail(c, NERF_ERR_INVALID, "coarse samples per ray must be greater than 0"); // src/lib.rs:483-486
     if (o->n_fine < 0) return fail(c, NERF_ERR_INVALID, "fine samples per ray must be >= 0");
     for (int r : o->reserved) if (r != 0) return fail(c, NERF_ERR_INVALID, "reserved option fields must be 0");
+    if (o->mlp_dtype != NERF_MLP_F32 && o->mlp_dtype != NERF_MLP_BF16) return fail(c, NERF_ERR_INVALID, "mlp_dtype must be NERF_MLP_F32 or NERF_MLP_BF16");
+    const bool bf16 = o->mlp_dtype == NERF_MLP_BF16;
     if (!c->net[NERF_NET_COARSE].loaded) return fail(c, NERF_ERR_STATE, "coarse network not loaded");
     if (!o->coarse_only && !c->net[NERF_NET_FINE].loaded) return fail(c, NERF_ERR_STATE, "fine network not loaded");
     const int s = o->ssaa > 1 ? o->ssaa : 1;
@@ -233,12 +275,12 @@ int render_device(nerf_ctx *c, const nerf_camera *cam, const nerf_render_opts *o
         a.ray_dirs = c->d_dirs;
         a.origin[0] = cam->pos[0]; a.origin[1] = cam->pos[1]; a.origin[2] = cam->pos[2];
         // coarse network: sigma only unless its colours are composited (reference discards them, src/lib.rs:404)
-        a.wstream = NC.wstream; a.small_params = NC.small;
+        a.wstream = bf16 ? (const float *)NC.wstream_bf16 : NC.wstream; a.small_params = NC.small;
         a.n_points = n_rays * nc; a.samples_per_ray = nc; a.t = c->d_tc;
         a.sigma_out = c->d_sc; a.rgb_out = c->d_rgbc;
         {
             Timed t(c, st, o->coarse_only ? 1 : 0, (uint64_t)a.n_points, timing);
-            HIP_TRY(c, nerf_mlp_launch(a, o->coarse_only != 0, c->n_cus, st));
+            HIP_TRY(c, (bf16 ? nerf_mlp_bf16_launch : nerf_mlp_launch)(a, o->coarse_only != 0, c->n_cus, st));
             t.done(c->last_render);
         }
         float *pass_out = ray_out + (size_t)row * RW * 3;
@@ -262,14 +304,14 @@ int render_device(nerf_ctx *c, const nerf_camera *cam, const nerf_render_opts *o
             t.done(c->last_render);
             t_fine = c->d_tf;
         }
-        a.wstream = NF.wstream; a.small_params = NF.small;
+        a.wstream = bf16 ? (const float *)NF.wstream_bf16 : NF.wstream; a.small_params = NF.small;
         a.n_points = n_rays * M; a.samples_per_ray = M; a.t = t_fine;
         a.sigma_out = c->d_sf; a.rgb_out = c->d_rgbf;
         a.clock_out = c->d_clock; // NULL unless NERF_DEBUG_CLOCK=1
         c->clock_valid = c->d_clock != nullptr;
         {
             Timed t(c, st, 1, (uint64_t)a.n_points, timing);
-            HIP_TRY(c, nerf_mlp_launch(a, true, c->n_cus, st));
+            HIP_TRY(c, (bf16 ? nerf_mlp_bf16_launch : nerf_mlp_launch)(a, true, c->n_cus, st));
             t.done(c->last_render);
         }
         ca.n = M; ca.t = t_fine; ca.sigma = c->d_sf; ca.rgb = c->d_rgbf;
@@ -348,6 +390,7 @@ int nerf_create(int device_id, nerf_ctx **out) {
         if (atoi(env) > 0 && hipMalloc((void **)&c->d_clock, (size_t)c->n_cus * 2 * sizeof(unsigned long long)) != hipSuccess) c->d_clock = nullptr;
     }
     hipError_t e1 = nerf_mlp_init();
+    if (e1 == hipSuccess) e1 = nerf_mlp_bf16_init();
     hipError_t e2 = e1 == hipSuccess ? sampling_init() : e1;
     hipError_t e3 = e2 == hipSuccess ? hipStreamCreate(&c->stream) : e2;
     if (e3 != hipSuccess) {
@@ -363,7 +406,7 @@ void nerf_destroy(nerf_ctx *c) {
     if (!c) return;
     DeviceGuard dg(c->device);
     (void)hipDeviceSynchronize();
-    for (auto &n : c->net) { if (n.wstream) (void)hipFree(n.wstream); if (n.small) (void)hipFree(n.small); }
+    for (auto &n : c->net) { if (n.wstream) (void)hipFree(n.wstream); if (n.small) (void)hipFree(n.small); if (n.wstream_bf16) (void)hipFree(n.wstream_bf16); }
     float *ptrs[] = {c->d_dirs, c->d_tc, c->d_sc, c->d_rgbc, c->d_tf, c->d_sf, c->d_rgbf, c->d_rayfb, c->d_out};
     for (float *p : ptrs) if (p) (void)hipFree(p);
     if (c->d_scratch) (void)hipFree(c->d_scratch);
@@ -456,7 +499,8 @@ int nerf_load_network_blob(nerf_ctx *c, int which, const char *blob_path) {
                     hdr[1] == nw + ns && fread(ws.data(), 4, nw, f) == nw && fread(sm.data(), 4, ns, f) == ns && fgetc(f) == EOF;
     fclose(f);
     if (!ok) return fail(c, NERF_ERR_SHAPE, std::string("not a version-1 packed network blob for this build: ") + blob_path);
-    return upload_packed(c, which, ws, sm);
+    const int rc = upload_packed(c, which, ws, sm);
+    return rc ? rc : bf16_from_f32_stream(c, which, ws);
 }
 
 int nerf_camera_from_pose(const float c2w[12], float ref_h, float ref_w, float focal, float near_, float far_, int width,
@@ -501,8 +545,16 @@ int nerf_debug_pack_network_dir(const char *dir, float *wstream, size_t wstream_
     return NERF_OK;
 }
 
+static int forward_device(nerf_ctx *c, int which, int dtype, const float *d_pts, const float *d_dirs, size_t n, float *d_rgb,
+                          float *d_sigma, void *stream);
+
 int nerf_forward_batch_device(nerf_ctx *c, int which, const float *d_pts, const float *d_dirs, size_t n, float *d_rgb,
                               float *d_sigma, void *stream) {
+    return forward_device(c, which, NERF_MLP_F32, d_pts, d_dirs, n, d_rgb, d_sigma, stream);
+}
+
+static int forward_device(nerf_ctx *c, int which, int dtype, const float *d_pts, const float *d_dirs, size_t n, float *d_rgb,
+                          float *d_sigma, void *stream) {
     if (!c) return fail(nullptr, NERF_ERR_INVALID, "ctx is NULL");
     if (which != NERF_NET_COARSE && which != NERF_NET_FINE) return fail(c, NERF_ERR_INVALID, "which must be NERF_NET_COARSE or NERF_NET_FINE");
     if (n == 0) return NERF_OK; // src/network.rs:199-201
@@ -512,13 +564,19 @@ int nerf_forward_batch_device(nerf_ctx *c, int which, const float *d_pts, const 
     DeviceGuard dg(c->device);
     MlpArgs a{};
     a.mode = MLP_MODE_POINTS;
-    a.wstream = c->net[which].wstream; a.small_params = c->net[which].small;
+    if (dtype != NERF_MLP_F32 && dtype != NERF_MLP_BF16) return fail(c, NERF_ERR_INVALID, "mlp_dtype must be NERF_MLP_F32 or NERF_MLP_BF16");
+    const bool bf16 = dtype == NERF_MLP_BF16;
+    a.wstream = bf16 ? (const float *)c->net[which].wstream_bf16 : c->net[which].wstream; a.small_params = c->net[which].small;
     a.n_points = (int)n; a.pts_soa = d_pts; a.dirs_aos = d_dirs; a.sigma_out = d_sigma; a.rgb_out = d_rgb;
-    HIP_TRY(c, nerf_mlp_launch(a, true, c->n_cus, (hipStream_t)stream));
+    HIP_TRY(c, (bf16 ? nerf_mlp_bf16_launch : nerf_mlp_launch)(a, true, c->n_cus, (hipStream_t)stream));
     return NERF_OK;
 }
 
 int nerf_forward_batch(nerf_ctx *c, int which, const float *pts, const float *dirs, size_t n, float *rgb, float *sigma) {
+    return nerf_forward_batch_ex(c, which, NERF_MLP_F32, pts, dirs, n, rgb, sigma);
+}
+
+int nerf_forward_batch_ex(nerf_ctx *c, int which, int dtype, const float *pts, const float *dirs, size_t n, float *rgb, float *sigma) {
     if (!c) return fail(nullptr, NERF_ERR_INVALID, "ctx is NULL");
     if (n == 0) return NERF_OK;
     if (!pts || !dirs || !rgb || !sigma) return fail(c, NERF_ERR_INVALID, "NULL buffer");
@@ -528,7 +586,7 @@ int nerf_forward_batch(nerf_ctx *c, int which, const float *pts, const float *di
     float *d_pts = (float *)c->d_scratch, *d_dirs = d_pts + 3 * n, *d_rgb = d_dirs + 3 * n, *d_sig = d_rgb + 3 * n;
     HIP_TRY(c, hipMemcpyAsync(d_pts, pts, 3 * n * sizeof(float), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipMemcpyAsync(d_dirs, dirs, 3 * n * sizeof(float), hipMemcpyHostToDevice, c->stream));
-    if ((rc = nerf_forward_batch_device(c, which, d_pts, d_dirs, n, d_rgb, d_sig, c->stream))) return rc;
+    if ((rc = forward_device(c, which, dtype, d_pts, d_dirs, n, d_rgb, d_sig, c->stream))) return rc;
     HIP_TRY(c, hipMemcpyAsync(rgb, d_rgb, 3 * n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipMemcpyAsync(sigma, d_sig, n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));

@@ -295,6 +295,73 @@ void oracle_forward_batch(const oracle_net *net, const float *pts, const float *
     free(buf);
 }
 
+/* ---- bf16-operand emulation (NOT in the reference): checks the arithmetic of the bf16 MFMA kernel (BASELINE config
+ * C5).  Weights and every matrix-layer input (encodings, ReLU'd hidden activations, bottleneck output, direction
+ * encodings) are rounded to bf16 (round-to-nearest-even); products accumulate in f32 from the bias, k ascending; the
+ * alpha and rgb heads read the UNROUNDED f32 activations with f32 weights, exactly as the kernel's VALU heads do. */
+static float bf16_round(float v) {
+    uint32_t u;
+    memcpy(&u, &v, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return v;
+    u += 0x7fffu + ((u >> 16) & 1u);
+    u &= 0xffff0000u;
+    memcpy(&v, &u, 4);
+    return v;
+}
+
+static void round_rows(float *buf, int rows, size_t ld, size_t B) {
+    for (int r = 0; r < rows; ++r)
+        for (size_t b = 0; b < B; ++b) buf[(size_t)r * ld + b] = bf16_round(buf[(size_t)r * ld + b]);
+}
+
+static void layer_forward_bf16w(const o_layer *L, const float *h, size_t ldh, size_t B, float *out, size_t ldo, int act) {
+    const int K = L->K, N = L->N;
+    for (int n = 0; n < N; ++n) {
+        float *o = out + (size_t)n * ldo;
+        const float bias = L->b[n];
+        for (size_t b = 0; b < B; ++b) o[b] = bias;
+        for (int k = 0; k < K; ++k) {
+            const float a = bf16_round(L->w[(size_t)k * N + n]);
+            const float *hr = h + (size_t)k * ldh;
+            for (size_t b = 0; b < B; ++b) o[b] = o[b] + a * hr[b]; /* bf16 x bf16 is exact in f32 */
+        }
+        for (size_t b = 0; b < B; ++b) o[b] = act_apply(o[b], act);
+    }
+}
+
+void oracle_forward_batch_bf16(const oracle_net *net, const float *pts, const float *dirs, size_t n, float *rgb, float *sigma) {
+    if (n == 0) return;
+    float *buf = (float *)malloc(sizeof(float) * (size_t)OB * (319 + 283 + 256 + 3 + 1));
+    float *cat = buf, *q = cat + 319 * OB, *h = q + 283 * OB, *c3 = h + 256 * OB, *sg = c3 + 3 * OB;
+    for (size_t c0 = 0; c0 < n; c0 += OB) {
+        const size_t B = (n - c0 < OB) ? n - c0 : OB;
+        encode_cols(pts + c0, pts + n + c0, pts + 2 * n + c0, 1, B, 10, cat, OB);
+        round_rows(cat, 63, OB, B);
+        float *x = h, *y = cat + 63 * OB;
+        layer_forward_bf16w(&net->dense[0], cat, OB, B, x, OB, ACT_RELU); round_rows(x, 256, OB, B);
+        layer_forward_bf16w(&net->dense[1], x, OB, B, y, OB, ACT_RELU); round_rows(y, 256, OB, B);
+        layer_forward_bf16w(&net->dense[2], y, OB, B, x, OB, ACT_RELU); round_rows(x, 256, OB, B);
+        layer_forward_bf16w(&net->dense[3], x, OB, B, y, OB, ACT_RELU); round_rows(y, 256, OB, B);
+        layer_forward_bf16w(&net->dense[4], y, OB, B, x, OB, ACT_RELU); round_rows(x, 256, OB, B);
+        memcpy(y, x, sizeof(float) * 256 * OB);
+        layer_forward_bf16w(&net->dense[5], cat, OB, B, x, OB, ACT_RELU); round_rows(x, 256, OB, B);
+        layer_forward_bf16w(&net->dense[6], x, OB, B, q, OB, ACT_RELU); round_rows(q, 256, OB, B);
+        layer_forward_bf16w(&net->dense[7], q, OB, B, x, OB, ACT_RELU);          /* h8 stays f32 for the alpha head */
+        layer_forward_blocked(&net->alpha, x, OB, B, sg, OB, ACT_RELU);
+        round_rows(x, 256, OB, B);
+        layer_forward_bf16w(&net->bottleneck, x, OB, B, q, OB, ACT_NONE); round_rows(q, 256, OB, B);
+        encode_cols(dirs + 3 * c0, dirs + 3 * c0 + 1, dirs + 3 * c0 + 2, 3, B, 4, q + 256 * OB, OB);
+        round_rows(q + 256 * OB, 27, OB, B);
+        layer_forward_bf16w(&net->viewdirs, q, OB, B, x, OB, ACT_RELU);
+        layer_forward_blocked(&net->rgb, x, OB, B, c3, OB, ACT_SIGMOID);          /* f32 head on f32 activations */
+        for (size_t c = 0; c < B; ++c) {
+            rgb[3 * (c0 + c)] = c3[c]; rgb[3 * (c0 + c) + 1] = c3[OB + c]; rgb[3 * (c0 + c) + 2] = c3[2 * OB + c];
+            sigma[c0 + c] = sg[c];
+        }
+    }
+    free(buf);
+}
+
 /* ------------------------------------------------------------------------------------------
  * Vec3 helpers (src/vec3.rs:15-34)
  * ---------------------------------------------------------------------------------------- */

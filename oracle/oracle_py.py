@@ -61,6 +61,7 @@ def lib():
         L.oracle_philox4x32.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                         C.POINTER(C.c_uint32)]
         L.oracle_forward_batch.argtypes = [C.c_void_p, f32p, f32p, C.c_size_t, f32p, f32p, C.c_int]
+        L.oracle_forward_batch_bf16.argtypes = [C.c_void_p, f32p, f32p, C.c_size_t, f32p, f32p]
         L.oracle_positional_encoding.argtypes = [f32p, C.c_size_t, C.c_int, f32p]
         L.oracle_camera_from_values.argtypes = [C.c_float, C.c_float, f32p, f32p, f32p, f32p, C.c_int, C.c_int,
                                                 C.POINTER(Camera)]
@@ -111,6 +112,14 @@ class Net:
         rgb = np.empty((n, 3), np.float32)
         sig = np.empty((n,), np.float32)
         lib().oracle_forward_batch(self.h, _p(pts), _p(dirs), n, _p(rgb), _p(sig), int(naive))
+        return rgb, sig
+
+    def forward_batch_bf16(self, pts_soa, dirs_aos):
+        """bf16-operand / f32-accumulate emulation (checker of the bf16 kernel; not reference behaviour)."""
+        pts = _f32(pts_soa); dirs = _f32(dirs_aos)
+        n = pts.shape[1]
+        rgb = np.empty((n, 3), np.float32); sig = np.empty((n,), np.float32)
+        lib().oracle_forward_batch_bf16(self.h, _p(pts), _p(dirs), n, _p(rgb), _p(sig))
         return rgb, sig
 
     def __del__(self):
