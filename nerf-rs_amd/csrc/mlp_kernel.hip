@@ -53,6 +53,9 @@ using namespace nerfmlp;
 #ifndef NERF_LDS_GROUP
 #define NERF_LDS_GROUP 1 // A operands are fetched from LDS for this many macro-steps per burst (1, 2 or 4)
 #endif
+#ifndef NERF_PIN_CHAINS
+#define NERF_PIN_CHAINS 0 // 1: zero-instruction asm touching all accumulators after every input tile (keeps MFMA chains in program order)
+#endif
 #ifndef NERF_LOOP_LAYERS
 #define NERF_LOOP_LAYERS 0 // (measured slower: 87.1 % vs 87.8 %; kept for the record) 1: dense1..7 + bottleneck as a runtime loop over 4 layer pairs (instruction-cache resident)
 #endif
@@ -299,6 +302,12 @@ __device__ __forceinline__ void tile_steps(const f32x16 &in, f32x16 (&out)[NT], 
             out[2] = MFMA(a1[2], b1, out[2]); out[3] = MFMA(a1[3], b1, out[3]);
         }
     }
+#endif
+#if NERF_PIN_CHAINS
+    if constexpr (NT == 8)
+        asm volatile("" : "+a"(out[0]), "+a"(out[1]), "+a"(out[2]), "+a"(out[3]), "+a"(out[4]), "+a"(out[5]), "+a"(out[6]), "+a"(out[7]));
+    else
+        asm volatile("" : "+a"(out[0]), "+a"(out[1]), "+a"(out[2]), "+a"(out[3]));
 #endif
 }
 

@@ -24,6 +24,20 @@
 
 using namespace nerfmlp;
 
+// Timing-only diagnostics (results are WRONG with any of these set; never shipped)
+#ifndef NERF_BDIAG_NO_BARRIER
+#define NERF_BDIAG_NO_BARRIER 0
+#endif
+#ifndef NERF_BDIAG_NO_DMA
+#define NERF_BDIAG_NO_DMA 0
+#endif
+#ifndef NERF_BDIAG_NO_LDS
+#define NERF_BDIAG_NO_LDS 0
+#endif
+#ifndef NERF_BDIAG_NO_BPREP
+#define NERF_BDIAG_NO_BPREP 0
+#endif
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -42,7 +56,7 @@ struct PipeB {
     const LDS_AS char *rd_base;   // LDS address (incl. lane*16) of the chunk the next macro-step to fetch lives in
     const LDS_AS char *ring_lane; // ring base + lane*16
     uint32_t rd_slot_off;
-    bf16x8 nx[8];                 // prefetched A operands of the next macro-step
+    bf16x8 nx[4];                 // prefetched A operands of the next HALF macro-step (4 MFMAs)
     uint32_t ring_addr;           // LDS byte address of the ring + wave*8 KiB (DMA destination base)
     uint32_t wr_slot_off, next_off, stream_bytes;
     const char *gbase;            // stream + wave*8 KiB
@@ -75,27 +89,48 @@ __device__ __forceinline__ void pipe_next_chunk(PipeB &P) {
 }
 
 // this wave's 8 KiB of the chunk = 8 pieces; piece i
-__device__ __forceinline__ void pipe_issue_piece(PipeB &P, int i) { glds_piece(P.lane16, P.cur_src + i * 1024, P.cur_dst + i * 1024); }
+__device__ __forceinline__ void pipe_issue_piece(PipeB &P, int i) {
+#if !NERF_BDIAG_NO_DMA
+    glds_piece(P.lane16, P.cur_src + i * 1024, P.cur_dst + i * 1024);
+#else
+    (void)P; (void)i;
+#endif
+}
 
-// Macro-step `ms` (0..3 within its chunk) begins: at ms == 2 the chunk after this one must have landed and the slot of
-// the previous chunk may be refilled; then fetch the A operands of the NEXT macro-step.
-__device__ __forceinline__ void pipe_begin(PipeB &P, int ms, bf16x8 (&a)[8]) {
-    if (ms == 2) {
+// Half `hf` (0/1) of macro-step `ms` (0..3 within its chunk) begins.  At (ms == 2, hf == 0) the chunk after this one
+// must have landed and the slot of the previous chunk may be refilled.  Takes the 4 prefetched A operands and starts
+// fetching the next 4 (the other half of this macro-step, or the first half of the next one).  Only 4 + 4 operand
+// fragments are live at a time: 8 + 8 cost 32 more VGPRs and made the full-head kernel spill.
+__device__ __forceinline__ void pipe_half(PipeB &P, int ms, int hf, bf16x8 (&a)[4]) {
+    if (ms == 2 && hf == 0) {
+#if NERF_BDIAG_NO_BARRIER
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
         asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
         pipe_next_chunk(P);
     }
 #pragma unroll
-    for (int j = 0; j < 8; ++j) a[j] = P.nx[j];
-    int nxt = ms + 1;
-    if (nxt == 4) {
-        uint32_t off = P.rd_slot_off + kCB;
-        off = (off == kRS * kCB) ? 0u : off;
-        P.rd_slot_off = off;
-        P.rd_base = P.ring_lane + off;
-        nxt = 0;
+    for (int j = 0; j < 4; ++j) a[j] = P.nx[j];
+    int nms = ms, nhf = hf + 1;
+    if (nhf == 2) {
+        nhf = 0;
+        nms = ms + 1;
+        if (nms == 4) {
+            uint32_t off = P.rd_slot_off + kCB;
+            off = (off == kRS * kCB) ? 0u : off;
+            P.rd_slot_off = off;
+            P.rd_base = P.ring_lane + off;
+            nms = 0;
+        }
     }
+#if NERF_BDIAG_NO_LDS
 #pragma unroll
-    for (int j = 0; j < 8; ++j) P.nx[j] = *(const LDS_AS bf16x8 *)(P.rd_base + nxt * kMS + j * 1024);
+    for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(P.nx[j]));
+#else
+#pragma unroll
+    for (int j = 0; j < 4; ++j) P.nx[j] = *(const LDS_AS bf16x8 *)(P.rd_base + nms * kMS + (nhf * 4 + j) * 1024);
+#endif
     __builtin_amdgcn_sched_barrier(0);
 }
 
@@ -116,15 +151,30 @@ __device__ __forceinline__ float relu(float v) {
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
 
 // B fragment of k-step s: registers 8s .. 8s+7 of the tile -> 8 bf16 (element j = register 8s + j).
+// The sources are pinned by an empty asm volatile so that hipcc cannot hoist the conversions of a whole layer's input
+// tiles to the top of the layer (that cost 130 spilled VGPRs in the viewdirs layer).  ReLU is applied AFTER the
+// conversion as one packed signed-16-bit max per pair (a negative bf16 is a negative int16; rounding keeps the sign).
 template <bool RELU>
 __device__ __forceinline__ bf16x8 make_b(const f32x16 &in, int s) {
+    float x[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) x[j] = in[8 * s + j];
+    asm volatile("" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]));
     bf16x8 b;
+#if NERF_BDIAG_NO_BPREP
+    b = __builtin_bit_cast(bf16x8, f32x4{x[0], x[1], x[2], x[3]});
+    return b;
+#endif
+    typedef short s16x2 __attribute__((ext_vector_type(2)));
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        float x = in[8 * s + 2 * q], y = in[8 * s + 2 * q + 1];
-        if (RELU) { x = relu(x); y = relu(y); }
-        const f32x2 p = {x, y};
-        const bf16x2 c = __builtin_convertvector(p, bf16x2);
+        const f32x2 p = {x[2 * q], x[2 * q + 1]};
+        bf16x2 c = __builtin_convertvector(p, bf16x2);
+        if (RELU) {
+            s16x2 i = __builtin_bit_cast(s16x2, c);
+            i = __builtin_elementwise_max(i, (s16x2){0, 0});
+            c = __builtin_bit_cast(bf16x2, i);
+        }
         b[2 * q] = c[0];
         b[2 * q + 1] = c[1];
     }
@@ -132,45 +182,59 @@ __device__ __forceinline__ bf16x8 make_b(const f32x16 &in, int s) {
 }
 
 // One input tile (32 features) of a layer with NT output tiles.  MS0 = macro-step (within its chunk) the tile starts at.
-template <int NT, bool RELU, int MS0>
-__device__ __forceinline__ void tile_steps(const f32x16 &in, f32x16 (&out)[NT], PipeB &P) {
+template <int NT, bool RELU, int MS0, bool ACC_IN = true>
+__device__ __forceinline__ void tile_steps(f32x16 &in, f32x16 (&out)[8], PipeB &P) { // NT = tiles of `out` in use
+    // Pin the source tile where it is consumed: this volatile asm "redefines" the accumulator tuple, so the 16
+    // v_accvgpr_reads below cannot be hoisted above it (hipcc otherwise hoists the reads of ALL input tiles of the
+    // viewdirs layer to its start: 128 extra live VGPRs, 128 spills).  Encoding tiles live in VGPRs: no pin.
+    if constexpr (ACC_IN) asm volatile("" : "+a"(in));
     const bf16x8 b0 = make_b<RELU>(in, 0), b1 = make_b<RELU>(in, 1);
     __builtin_amdgcn_sched_barrier(0);
-    bf16x8 a[8];
+    bf16x8 a[4];
     if constexpr (NT == 8) {
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             const bf16x8 b = s ? b1 : b0;
-            pipe_begin(P, MS0 + s, a);
+            pipe_half(P, MS0 + s, 0, a);
             out[0] = MFMA16(a[0], b, out[0]); out[1] = MFMA16(a[1], b, out[1]);
             pipe_dma(P, MS0 + s, 0);
             out[2] = MFMA16(a[2], b, out[2]); out[3] = MFMA16(a[3], b, out[3]);
-            out[4] = MFMA16(a[4], b, out[4]); out[5] = MFMA16(a[5], b, out[5]);
+            pipe_half(P, MS0 + s, 1, a);
+            out[4] = MFMA16(a[0], b, out[4]); out[5] = MFMA16(a[1], b, out[5]);
             pipe_dma(P, MS0 + s, 1);
-            out[6] = MFMA16(a[6], b, out[6]); out[7] = MFMA16(a[7], b, out[7]);
+            out[6] = MFMA16(a[2], b, out[6]); out[7] = MFMA16(a[3], b, out[7]);
         }
     } else {
-        pipe_begin(P, MS0, a);
+        pipe_half(P, MS0, 0, a);
         out[0] = MFMA16(a[0], b0, out[0]); out[1] = MFMA16(a[1], b0, out[1]);
         pipe_dma(P, MS0, 0);
         out[2] = MFMA16(a[2], b0, out[2]); out[3] = MFMA16(a[3], b0, out[3]);
-        out[0] = MFMA16(a[4], b1, out[0]); out[1] = MFMA16(a[5], b1, out[1]);
+        pipe_half(P, MS0, 1, a);
+        out[0] = MFMA16(a[0], b1, out[0]); out[1] = MFMA16(a[1], b1, out[1]);
         pipe_dma(P, MS0, 1);
-        out[2] = MFMA16(a[6], b1, out[2]); out[3] = MFMA16(a[7], b1, out[3]);
+        out[2] = MFMA16(a[2], b1, out[2]); out[3] = MFMA16(a[3], b1, out[3]);
     }
+    // Keep every accumulation chain in program order: without this data dependence hipcc defers the whole chain of
+    // some output tiles by hundreds of MFMAs (sched_barrier does not stop it), keeping their A operands alive --
+    // which it then spills and reloads in front of each deferred MFMA.  Zero instructions.
+    if constexpr (NT == 8)
+        asm volatile("" : "+a"(out[0]), "+a"(out[1]), "+a"(out[2]), "+a"(out[3]), "+a"(out[4]), "+a"(out[5]), "+a"(out[6]), "+a"(out[7]));
+    else
+        asm volatile("" : "+a"(out[0]), "+a"(out[1]), "+a"(out[2]), "+a"(out[3]));
 }
 
 // A macro-step of stream padding: keep the pipeline bookkeeping (sync, prefetch, DMA), no matrix work.
 template <int MS>
 __device__ __forceinline__ void skip_macro_step(PipeB &P) {
-    bf16x8 a[8];
-    pipe_begin(P, MS, a);
+    bf16x8 a[4];
+    pipe_half(P, MS, 0, a);
     pipe_dma(P, MS, 0);
+    pipe_half(P, MS, 1, a);
     pipe_dma(P, MS, 1);
 }
 
 template <int NT>
-__device__ __forceinline__ void load_bias(f32x16 (&out)[NT], const LDS_AS float *bias, int h) {
+__device__ __forceinline__ void load_bias(f32x16 (&out)[8], const LDS_AS float *bias, int h) {
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const LDS_AS f32x4 *b = (const LDS_AS f32x4 *)(bias + (nt * 2 + h) * 16);
@@ -183,7 +247,7 @@ __device__ __forceinline__ void load_bias(f32x16 (&out)[NT], const LDS_AS float 
 }
 
 template <bool RELU>
-__device__ __forceinline__ void hidden_layer(const f32x16 (&in)[8], f32x16 (&out)[8], const LDS_AS float *bias, PipeB &P, int h) {
+__device__ __forceinline__ void hidden_layer(f32x16 (&in)[8], f32x16 (&out)[8], const LDS_AS float *bias, PipeB &P, int h) {
     load_bias<8>(out, bias, h);
     tile_steps<8, RELU, 0>(in[0], out, P); tile_steps<8, RELU, 2>(in[1], out, P);
     tile_steps<8, RELU, 0>(in[2], out, P); tile_steps<8, RELU, 2>(in[3], out, P);
@@ -213,6 +277,8 @@ __device__ __forceinline__ void fast_sincos(float x, float *s_out, float *c_out)
 
 __device__ __forceinline__ float xhalf_sum(float v) { return v + __shfl_xor(v, 32, 64); }
 
+// alpha head on the VALU (f32): sigma = relu(b + sum_F w[F] relu(h8[F])).  The reads of each accumulator tile are pinned
+// (empty asm volatile) so that hipcc does not hoist all 128 AGPR reads at once (spills next to the 64 A-operand VGPRs).
 __device__ __forceinline__ float alpha_head(const f32x16 (&Y)[8], const LDS_AS float *small, int h) {
     const LDS_AS f32x4 *w = (const LDS_AS f32x4 *)(small + kAlphaWOff + h * 128);
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
@@ -220,11 +286,13 @@ __device__ __forceinline__ float alpha_head(const f32x16 (&Y)[8], const LDS_AS f
     for (int t = 0; t < 8; ++t) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
+            float x0 = Y[t][4 * q + 0], x1 = Y[t][4 * q + 1], x2 = Y[t][4 * q + 2], x3 = Y[t][4 * q + 3];
+            asm volatile("" : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3));
             const f32x4 wv = w[t * 4 + q];
-            a0 = fmaf(wv[0], relu(Y[t][4 * q + 0]), a0);
-            a1 = fmaf(wv[1], relu(Y[t][4 * q + 1]), a1);
-            a2 = fmaf(wv[2], relu(Y[t][4 * q + 2]), a2);
-            a3 = fmaf(wv[3], relu(Y[t][4 * q + 3]), a3);
+            a0 = fmaf(wv[0], relu(x0), a0);
+            a1 = fmaf(wv[1], relu(x1), a1);
+            a2 = fmaf(wv[2], relu(x2), a2);
+            a3 = fmaf(wv[3], relu(x3), a3);
         }
     }
     return fmaxf(xhalf_sum((a0 + a1) + (a2 + a3)) + small[kMiscOff + 0], 0.f);
@@ -271,7 +339,7 @@ __global__ __launch_bounds__(256, 1) void nerf_mlp_kernel_bf16(const MlpArgs A) 
     P.rd_slot_off = 0;
     P.rd_base = P.ring_lane;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) P.nx[j] = *(const LDS_AS bf16x8 *)(P.rd_base + j * 1024);
+    for (int j = 0; j < 4; ++j) P.nx[j] = *(const LDS_AS bf16x8 *)(P.rd_base + j * 1024);
 
     struct RawIn { float a, b, c, dx, dy, dz; };
     auto load_raw = [&](int tile_idx) -> RawIn {
@@ -323,15 +391,15 @@ __global__ __launch_bounds__(256, 1) void nerf_mlp_kernel_bf16(const MlpArgs A) 
 
         f32x16 X[8], Y[8];
         load_bias<8>(X, small + kBiasOff + 0 * 256, h);
-        tile_steps<8, false, 0>(E[0], X, P);
-        tile_steps<8, false, 2>(E[1], X, P);
+        tile_steps<8, false, 0, false>(E[0], X, P);
+        tile_steps<8, false, 2, false>(E[1], X, P);
         hidden_layer<true>(X, Y, small + kBiasOff + 1 * 256, P, h);
         hidden_layer<true>(Y, X, small + kBiasOff + 2 * 256, P, h);
         hidden_layer<true>(X, Y, small + kBiasOff + 3 * 256, P, h);
         hidden_layer<true>(Y, X, small + kBiasOff + 4 * 256, P, h);
         load_bias<8>(Y, small + kBiasOff + 5 * 256, h);
-        tile_steps<8, false, 0>(E[0], Y, P);
-        tile_steps<8, false, 2>(E[1], Y, P);
+        tile_steps<8, false, 0, false>(E[0], Y, P);
+        tile_steps<8, false, 2, false>(E[1], Y, P);
         tile_steps<8, true, 0>(X[0], Y, P); tile_steps<8, true, 2>(X[1], Y, P);
         tile_steps<8, true, 0>(X[2], Y, P); tile_steps<8, true, 2>(X[3], Y, P);
         tile_steps<8, true, 0>(X[4], Y, P); tile_steps<8, true, 2>(X[5], Y, P);
@@ -357,13 +425,15 @@ __global__ __launch_bounds__(256, 1) void nerf_mlp_kernel_bf16(const MlpArgs A) 
                 }
                 D[12] = h ? 0.f : dx; D[13] = h ? 0.f : dy; D[14] = h ? 0.f : dz; D[15] = 0.f;
             }
-            f32x16 V[4];
+            // viewdirs accumulates into Y[0..3]: Y is dead after the bottleneck, and saying so explicitly keeps hipcc
+            // from allocating a third accumulator set (which spilled 130 VGPRs)
+            f32x16 (&V)[8] = Y;
             load_bias<4>(V, small + kBiasViewOff, h);
             tile_steps<4, false, 0>(X[0], V, P); tile_steps<4, false, 1>(X[1], V, P);
             tile_steps<4, false, 2>(X[2], V, P); tile_steps<4, false, 3>(X[3], V, P);
             tile_steps<4, false, 0>(X[4], V, P); tile_steps<4, false, 1>(X[5], V, P);
             tile_steps<4, false, 2>(X[6], V, P); tile_steps<4, false, 3>(X[7], V, P);
-            tile_steps<4, false, 0>(D, V, P);
+            tile_steps<4, false, 0, false>(D, V, P);
             skip_macro_step<1>(P); skip_macro_step<2>(P); skip_macro_step<3>(P); // stream padding to the chunk end
             float c[3];
 #pragma unroll

@@ -8,12 +8,13 @@ sys.path.insert(0, ROOT)
 import nerf_rs_amd as N
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 size = int(sys.argv[2]) if len(sys.argv) > 2 else 800
+dtype = sys.argv[3] if len(sys.argv) > 3 else "f32"
 with N.Renderer(0) as r:
     r.load_scene(os.path.join(ROOT, "lego_rust"))
     cam = N.camera_from_samples(os.path.join(ROOT, "lego_rust", "tf_reference_samples.json"), size, size, 64)
     best = None
     for k in range(n):
-        img, st = N.render_image(r.coarse, r.fine, cam, 128, seed=0, return_stats=True)
+        img, st = N.render_image(r.coarse, r.fine, cam, 128, seed=0, dtype=dtype, return_stats=True)
         if best is None or st.ms_total < best.ms_total:
             best = st
     msg = ""
@@ -26,8 +27,9 @@ with N.Renderer(0) as r:
     mhz = C.c_double(0)
     if os.environ.get("NERF_DEBUG_CLOCK") and r._L.nerf_debug_shader_clock_mhz(r.handle, C.byref(mhz)) == 0:
         msg += f" clock {mhz.value:.0f} MHz"
+    peak = 2500.0 if dtype == "bf16" else 157.3
     fl = best.n_fine_points * 1186816 / (best.ms_fine_mlp * 1e-3) / 1e12
     cl = best.n_coarse_points * 982528 / (best.ms_coarse_mlp * 1e-3) / 1e12
     print(f"{os.path.basename(N.lib_path()):34s} total {best.ms_total:8.2f} ms  coarse {best.ms_coarse_mlp:7.2f} ({cl:6.2f} TF)  "
-          f"fine {best.ms_fine_mlp:8.2f} ({fl:6.2f} TF = {100 * fl / 157.3:5.2f}%)  other {best.ms_other:5.2f}  "
+          f"fine {best.ms_fine_mlp:8.2f} ({fl:6.2f} TF = {100 * fl / peak:5.2f}%)  other {best.ms_other:5.2f}  "
           f"rays/s {best.n_rays / best.ms_total * 1e3:9.0f}{msg}", flush=True)
