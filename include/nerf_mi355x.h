@@ -14,7 +14,9 @@
  * Conventions: every function returns 0 on success or a negative nerf_status; nerf_last_error() gives the
  * message (the reference panics instead: src/lib.rs:36,118,127,483-501).  The caller owns all in/out buffers;
  * the context owns device memory.  Plain pointers and sizes only -- no C++ / torch types.  A context is bound to
- * one HIP device and is single-caller (one frame at a time); create one context per GPU / per thread.
+ * one HIP device and is single-caller: one call at a time, and consecutive asynchronous calls (`*_device`) must use the
+ * same stream or be separated by a stream synchronisation -- they share the context's pass workspace.  Create one
+ * context per GPU / per thread.
  * Everything is f32.  Without the HIP runtime or a gfx950 device nerf_create fails (there is no CPU fallback).
  */
 #ifndef NERF_MI355X_H

@@ -209,14 +209,24 @@ int check_camera(nerf_ctx *c, const nerf_camera *cam) {
     return NERF_OK;
 }
 
-// Record kernel(s) between two events of the given kind.
+// Record kernel(s) between two events of the given kind.  If done() is never reached (a launch failed and the caller
+// returned early) the destructor hands the events back to the pool.
 struct Timed {
     nerf_ctx *c; hipStream_t st; EvPair p; bool on;
     Timed(nerf_ctx *c_, hipStream_t st_, int kind, uint64_t points, bool enable) : c(c_), st(st_), on(enable) {
-        p.kind = kind; p.points = points; p.a = p.b = nullptr;
-        if (on) { p.a = get_event(c); p.b = get_event(c); if (!p.a || !p.b) on = false; else (void)hipEventRecord(p.a, st); }
+        p.kind = kind; p.points = points; p.a = get_event(c); p.b = get_event(c);
+        if (!p.a || !p.b) on = false;
+        if (on) (void)hipEventRecord(p.a, st);
     }
-    void done(std::vector<EvPair> &dst) { if (on) { (void)hipEventRecord(p.b, st); dst.push_back(p); } }
+    Timed(const Timed &) = delete;
+    Timed &operator=(const Timed &) = delete;
+    void done(std::vector<EvPair> &dst) {
+        if (on) { (void)hipEventRecord(p.b, st); dst.push_back(p); p.a = p.b = nullptr; }
+    }
+    ~Timed() {
+        if (p.a) c->ev_pool.push_back(p.a);
+        if (p.b) c->ev_pool.push_back(p.b);
+    }
 };
 
 int render_device(nerf_ctx *c, const nerf_camera *cam, const nerf_render_opts *o, float *d_out, hipStream_t st,
@@ -242,7 +252,8 @@ int render_device(nerf_ctx *c, const nerf_camera *cam, const nerf_render_opts *o
     // then runs on the coarse samples only
     const int nf = (o->coarse_only || o->n_fine == 0 || nc < 3) ? 0 : o->n_fine;
     const int M = nc + nf;
-    if ((size_t)M * 7 * 4 * sizeof(float) > 160 * 1024) return fail(c, NERF_ERR_INVALID, "too many samples per ray for the compositing kernel");
+    if (composite_lds_bytes(M) > 160 * 1024 || (nf > 0 && resample_lds_bytes(nc, nf) > 160 * 1024))
+        return fail(c, NERF_ERR_INVALID, "too many samples per ray for the sampling / compositing kernels (one ray per wave in LDS)");
     const int RW = cw * s, RH = ch * s, RX0 = x0 * s, RY0 = y0 * s;
     // a pass must keep rays * samples within int32 (kernel indices) as well as within the configured budget
     const size_t pass_cap = std::min<size_t>(c->max_rays_per_pass, (size_t)0x3fffffff / (size_t)M);
@@ -308,7 +319,7 @@ int render_device(nerf_ctx *c, const nerf_camera *cam, const nerf_render_opts *o
         a.n_points = n_rays * M; a.samples_per_ray = M; a.t = t_fine;
         a.sigma_out = c->d_sf; a.rgb_out = c->d_rgbf;
         a.clock_out = c->d_clock; // NULL unless NERF_DEBUG_CLOCK=1
-        c->clock_valid = c->d_clock != nullptr;
+        c->clock_valid = c->d_clock != nullptr && !bf16; // only the f32 kernel writes the stamps
         {
             Timed t(c, st, 1, (uint64_t)a.n_points, timing);
             HIP_TRY(c, (bf16 ? nerf_mlp_bf16_launch : nerf_mlp_launch)(a, true, c->n_cus, st));

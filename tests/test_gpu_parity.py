@@ -410,3 +410,32 @@ def test_bf16_render_gate2(renderer, native, samples):
     out = np.empty((crop[3], crop[2], 3), np.float32)
     rc = renderer._L.nerf_render_image(renderer.handle, C.byref(cam.c), C.byref(o), out.ctypes.data_as(C.POINTER(C.c_float)), None)
     assert rc == -1 and b"mlp_dtype" in renderer._L.nerf_last_error(renderer.handle)
+
+
+def test_load_network_tensors_entry_point(renderer, native):
+    """nerf_load_network_tensors: the path for a host that reads the .bin files itself (Rust's load_tensor,
+    src/lib.rs:34-42) and hands over named tensors; same name/shape checks as the directory loader."""
+    import ctypes as C
+    g = golden("forward_batch_4096.npz")
+    f32p = C.POINTER(C.c_float)
+    with native.Renderer(0) as r2:
+        for which, sub in ((0, "coarse"), (1, "fine")):
+            names, dims, arrs = [], [], []
+            for line in open(os.path.join(SCENE, sub, "shapes.txt")):
+                parts = line.split()
+                names.append(parts[0]); d = [int(x) for x in parts[1:]]
+                dims += [d[0], d[1] if len(d) > 1 else 0]
+                arrs.append(np.fromfile(os.path.join(SCENE, sub, parts[0] + ".bin"), dtype="<f4"))
+            n = len(names)
+            c_names = (C.c_char_p * n)(*[s.encode() for s in names])
+            c_dims = (C.c_int64 * (2 * n))(*dims)
+            c_data = (f32p * n)(*[a.ctypes.data_as(f32p) for a in arrs])
+            assert r2._L.nerf_load_network_tensors(r2.handle, which, n, c_names, c_dims, c_data) == 0
+            out = native.Network(r2, which).forward_batch(g["pts"][:, :512], g["dirs"][:512])
+            ref = (renderer.coarse if which == 0 else renderer.fine).forward_batch(g["pts"][:, :512], g["dirs"][:512])
+            assert np.array_equal(out[0], ref[0]) and np.array_equal(out[1], ref[1])
+        # one tensor short -> "missing ... parameter" (src/lib.rs:118,127); a wrong shape -> dims mismatch
+        assert r2._L.nerf_load_network_tensors(r2.handle, 0, n - 1, c_names, c_dims, c_data) == -3
+        assert b"missing" in r2._L.nerf_last_error(r2.handle)
+        c_dims[1] = 255
+        assert r2._L.nerf_load_network_tensors(r2.handle, 0, n, c_names, c_dims, c_data) == -4
