@@ -439,3 +439,31 @@ def test_load_network_tensors_entry_point(renderer, native):
         assert b"missing" in r2._L.nerf_last_error(r2.handle)
         c_dims[1] = 255
         assert r2._L.nerf_load_network_tensors(r2.handle, 0, n, c_names, c_dims, c_data) == -4
+
+
+def test_odd_sample_counts_and_large_batches(renderer, native, oracle, oracle_nets, samples):
+    """Sample counts that are not multiples of the 32-point wave tile (a wave tile then spans several rays, the
+    per-lane ray index path) and a batch far larger than one pass of the persistent grid."""
+    cam = native.camera_from_samples(samples, 256, 256, 20)
+    ocam = oracle.camera_from_samples(samples, 256, 256)
+    crop = (121, 100, 13, 9)
+    img = native.render_image(renderer.coarse, renderer.fine, cam, 50, seed=9, crop=crop)          # 20 + 50 = 70 samples
+    ref = oracle.render_image(*oracle_nets, ocam, oracle.make_opts(20, 50, crop=crop, seed=9))
+    _gate1(img, ref)
+    cam3 = native.camera_from_samples(samples, 256, 256, 3)                                       # smallest count that resamples
+    img3 = native.render_image(renderer.coarse, renderer.fine, cam3, 5, seed=9, crop=crop)
+    ref3 = oracle.render_image(*oracle_nets, ocam, oracle.make_opts(3, 5, crop=crop, seed=9))
+    _gate1(img3, ref3)
+    cam2 = native.camera_from_samples(samples, 256, 256, 2)                                       # < 3 coarse samples: no resampling
+    img2 = native.render_image(renderer.coarse, renderer.fine, cam2, 5, seed=9, crop=crop)
+    ref2 = oracle.render_image(*oracle_nets, ocam, oracle.make_opts(2, 5, crop=crop, seed=9))
+    _gate1(img2, ref2)
+    # 3 M points through forward_batch: every 1000th point against the fixture values it repeats
+    g = golden("forward_batch_4096.npz")
+    reps = 733
+    pts = np.tile(g["pts"], (1, reps)); dirs = np.tile(g["dirs"], (reps, 1))
+    rgb, sg = renderer.fine.forward_batch(pts, dirs)
+    assert rgb.shape == (4096 * reps, 3)
+    base_rgb, base_sg = renderer.fine.forward_batch(g["pts"], g["dirs"])
+    assert np.array_equal(sg.reshape(reps, 4096), np.tile(base_sg, (reps, 1)))
+    assert np.array_equal(rgb.reshape(reps, 4096, 3)[::97], np.tile(base_rgb, (reps, 1, 1))[::97])
