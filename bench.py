@@ -99,6 +99,9 @@ def main():
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
                     help="MLP arithmetic: f32 = BASELINE's headline config (C3, default); bf16 = the C5 study (not the headline)")
     ap.add_argument("--ssaa", type=int, default=1, help="s x s rays per pixel (C5: --dtype bf16 --ssaa 2)")
+    ap.add_argument("--skip-empty", action="store_true",
+                    help="SURVEY 8f.2 (reported separately, not the headline): skip the colour head of all-empty tiles; "
+                         "the image is bit-identical, the roofline line then prices EXECUTED flops")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-naive", action="store_true", help="also time the reference's own loop order (minutes)")
     args = ap.parse_args()
@@ -131,10 +134,10 @@ def main():
     def step():
         if not use_dist:
             N.render_image(r.coarse, r.fine, cam, args.fine, seed=args.seed, ssaa=args.ssaa, dtype=args.dtype,
-                           device_out=frame.data_ptr(), stream=stream)
+                           skip_empty=args.skip_empty, device_out=frame.data_ptr(), stream=stream)
             return frame
         return N.render_image_distributed(r.coarse, r.fine, cam, args.fine, seed=args.seed, ssaa=args.ssaa, dtype=args.dtype,
-                                          return_tensor=True)
+                                          skip_empty=args.skip_empty, return_tensor=True)
 
     def fence():
         if use_dist:
@@ -151,6 +154,12 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     ms_dom, pts_dom, n_dom = r.kernel_time_query(reset=True)
+    skipped_per_launch = 0
+    if args.skip_empty and world == 1:  # one extra untimed frame with stats: the skip count is deterministic per frame
+        st = N.render_image(r.coarse, r.fine, cam, args.fine, seed=args.seed, ssaa=args.ssaa, dtype=args.dtype,
+                            skip_empty=True, device_out=frame.data_ptr(), stream=stream, return_stats=True)
+        skipped_per_launch = st.n_colour_skipped_points
+        r.kernel_time_query(reset=True)
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     if use_dist:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -162,7 +171,9 @@ def main():
         bf16 = args.dtype == "bf16"
         peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_FP32_MFMA_TFLOPS
         value = n_rays * args.steps / dt
-        ach = pts_dom * N.FLOP_PER_POINT_FULL / (ms_dom * 1e-3) / 1e12 if ms_dom > 0 else 0.0
+        # executed flops of the dominant launches: a skipped sample still runs dense0..7 + alpha (sigma-only cost)
+        flops_dom = pts_dom * N.FLOP_PER_POINT_FULL - n_dom * skipped_per_launch * (N.FLOP_PER_POINT_FULL - N.FLOP_PER_POINT_SIGMA)
+        ach = flops_dom / (ms_dom * 1e-3) / 1e12 if ms_dom > 0 else 0.0
         line = {  # noqa: E501
             "metric": "rays/sec, lego 800x800 (64 coarse + 128 fine samples per ray)", "value": value, "unit": "rays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
@@ -174,6 +185,7 @@ def main():
                                    f"lego coarse+fine hierarchical, {args.width}x{args.height}, {args.coarse}+{args.fine} "
                                    f"samples/ray, {args.dtype}, {world}xMI355X" + (", row bands + RCCL all-gather" if world > 1 else ""),
                        "rays_per_step": n_rays, "flop_per_ray": flop_ray, "seed": args.seed,
+                       "skip_empty": bool(args.skip_empty), "colour_head_skipped_samples_per_frame": skipped_per_launch,
                        "whole_job_fraction_of_mfma_roofline": value * flop_ray / (world * peak * 1e12)},
             "roofline": {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
                          "frac": ach / peak, "traffic": None if bf16 else pmc_traffic_bytes(),

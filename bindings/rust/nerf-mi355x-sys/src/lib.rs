@@ -35,7 +35,9 @@ pub struct nerf_render_opts {
     pub crop_h: i32,
     pub ssaa: i32,
     pub seed: u64,
-    pub reserved: [i32; 4],
+    pub mlp_dtype: i32,
+    pub skip_empty: i32,
+    pub reserved: [i32; 2],
 }
 
 #[repr(C)]
@@ -50,6 +52,7 @@ pub struct nerf_stats {
     pub ms_other: f64,
     pub n_mlp_launches: u32,
     pub n_passes: u32,
+    pub n_colour_skipped_points: u64,
 }
 
 pub const NERF_OK: c_int = 0;

@@ -66,7 +66,11 @@ typedef struct {
     uint64_t seed;        /* counter-RNG seed (reference: unseeded thread_rng, src/lib.rs:375,407) */
     int32_t mlp_dtype;    /* ext: NERF_MLP_F32 (0, default: exact-f32 MFMA, the parity path) or NERF_MLP_BF16 (1: bf16
                            * operands / f32 accumulate on the bf16 matrix cores -- BASELINE config C5; PSNR-level parity) */
-    int32_t reserved[3];  /* must be 0 */
+    int32_t skip_empty;   /* ext: 1 = skip the colour head (bottleneck + viewdirs + rgb, 17 % of a full MLP
+                           * evaluation) for every 128-sample tile whose densities are all 0.  EXACT: such samples have
+                           * alpha = 0 and weight 0, the image is bit-identical; only the work changes.  Default 0 so that
+                           * timings are plain executed-FLOP figures. */
+    int32_t reserved[2];  /* must be 0 */
 } nerf_render_opts;
 
 /* Device-side timing of the last render (HIP events on the render stream). */
@@ -78,6 +82,7 @@ typedef struct {
     double ms_other;       /* ray gen + sampling + compositing + downsample */
     uint32_t n_mlp_launches;
     uint32_t n_passes;
+    uint64_t n_colour_skipped_points; /* samples whose colour head was skipped (skip_empty) */
 } nerf_stats;
 
 /* ---- lifecycle ------------------------------------------------------------------------------------------ */

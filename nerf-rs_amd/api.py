@@ -204,17 +204,18 @@ def camera_from_pose(c2w, hwf, near, far, width, height, coarse_samples_per_ray=
 
 
 class RenderOpts:
-    def __init__(self, n_coarse=64, n_fine=128, coarse_only=False, crop=None, ssaa=1, seed=0, dtype="f32"):
+    def __init__(self, n_coarse=64, n_fine=128, coarse_only=False, crop=None, ssaa=1, seed=0, dtype="f32", skip_empty=False):
         self.n_coarse, self.n_fine, self.coarse_only, self.crop, self.ssaa, self.seed = \
             n_coarse, n_fine, coarse_only, crop, ssaa, seed
         self.dtype = _DTYPES[dtype]
+        self.skip_empty = bool(skip_empty)
 
     def to_c(self):
         o = COpts()
         o.n_coarse, o.n_fine, o.coarse_only = self.n_coarse, self.n_fine, int(self.coarse_only)
         if self.crop:
             o.crop_x0, o.crop_y0, o.crop_w, o.crop_h = self.crop
-        o.ssaa, o.seed, o.mlp_dtype = self.ssaa, self.seed, self.dtype
+        o.ssaa, o.seed, o.mlp_dtype, o.skip_empty = self.ssaa, self.seed, self.dtype, int(self.skip_empty)
         return o
 
     def out_shape(self, cam):
@@ -222,7 +223,7 @@ class RenderOpts:
 
 
 def render_image(coarse, fine, camera, fine_samples_per_ray=128, *, seed=0, coarse_only=False, crop=None, ssaa=1,
-                 dtype="f32", return_stats=False, device_out=None, stream=0):
+                 dtype="f32", skip_empty=False, return_stats=False, device_out=None, stream=0):
     """render_image (src/lib.rs:474-565) -> (h, w, 3) float32 linear RGB.
 
     coarse/fine: Network objects of one Renderer; camera.samples_per_ray is the coarse sample count.
@@ -231,7 +232,7 @@ def render_image(coarse, fine, camera, fine_samples_per_ray=128, *, seed=0, coar
     R = coarse.renderer
     if fine is not None and fine.renderer is not R:
         raise NerfError(-1, "coarse and fine networks must live in the same Renderer")
-    opts = RenderOpts(camera.samples_per_ray, fine_samples_per_ray, coarse_only, crop, ssaa, seed, dtype)
+    opts = RenderOpts(camera.samples_per_ray, fine_samples_per_ray, coarse_only, crop, ssaa, seed, dtype, skip_empty)
     o = opts.to_c()
     st = CStats()
     if device_out is not None:

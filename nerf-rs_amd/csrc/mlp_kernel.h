@@ -20,6 +20,8 @@ struct MlpArgs {
     // outputs
     float *sigma_out; // n
     float *rgb_out;   // n x 3 (full kernels only)
+    int skip_empty;                   // full kernels: skip the colour head of tiles whose 128 sigmas are all 0 (exact)
+    unsigned long long *skip_counter; // optional: number of skipped 128-point tiles (atomic)
     unsigned long long *clock_out; // optional diagnostic: per workgroup {shader cycles, 100 MHz ticks} of the tile loop
 };
 

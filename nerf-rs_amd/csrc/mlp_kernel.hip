@@ -160,6 +160,25 @@ __device__ __forceinline__ void pipe_mid_step(Pipe &P, int ms) {
 #endif
 }
 
+// Abandon the rest of the current tile's weight stream and start over at chunk 0 (empty-tile skipping).  Every wave
+// of the workgroup calls it at the same program point, right after a workgroup barrier, at a chunk boundary (all four
+// pieces of the last selected chunk have been issued).
+__device__ __forceinline__ void pipe_restart(Pipe &P) {
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory"); // in-flight chunks landed; nobody reads the ring now
+    P.next_off = 0;
+    P.wr_slot_off = 0;
+#pragma unroll
+    for (int c = 0; c < kRingSlots - 1; ++c) pipe_issue(P);
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    P.rd_slot_off = 0;
+    P.rd_base = P.ring_lane;
+#pragma unroll
+    for (int j = 0; j < NERF_LDS_GROUP; ++j) {
+        P.nx[2 * j] = *(const LDS_AS f32x4 *)(P.rd_base + j * 2048);
+        P.nx[2 * j + 1] = *(const LDS_AS f32x4 *)(P.rd_base + j * 2048 + 1024);
+    }
+}
+
 // Take the prefetched operands of macro-step `ms` (0..7 within its chunk) and start fetching those of the next one.
 // All in-chunk addressing is a per-chunk base + immediate offset: VALU instructions are NOT free next to fp32 MFMAs
 // (they share the vector datapath), so the ring arithmetic is one v_add per chunk plus scalar ops.
@@ -529,9 +548,30 @@ __global__ __launch_bounds__(256, 1) void nerf_mlp_kernel(const MlpArgs A) {
         hidden_layer<true>(Y, X, small + kBiasOff + 6 * 256, P, h);
         hidden_layer<true>(X, Y, small + kBiasOff + 7 * 256, P, h);
         sigma = alpha_head(Y, small, h);
+        if (valid && h == 0) A.sigma_out[i] = sigma;
+        if (FULL && A.skip_empty) {
+            // Empty-tile skip (exact): if sigma == 0 for all 128 points of this workgroup's tile, then
+            // alpha = 1 - exp(-0 * delta) = 0 and w = T * 0 = 0 exactly for each of them (src/lib.rs:271-272), so their
+            // colours never reach a pixel: skip bottleneck + viewdirs + rgb (17 % of a full evaluation), write rgb = 0.
+            LDS_AS int *vote = (LDS_AS int *)(lds + kRingSlots * kChunkBytes) + kMiscOff + 8;
+            const bool any_wave = __any(valid && sigma > 0.0f);
+            if (lane == 0) vote[wave] = any_wave ? 1 : 0;
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            const int any_wg = vote[0] | vote[1] | vote[2] | vote[3];
+            if (!any_wg) {
+                if (valid && h == 0) {
+                    A.rgb_out[3 * (size_t)i + 0] = 0.f; A.rgb_out[3 * (size_t)i + 1] = 0.f; A.rgb_out[3 * (size_t)i + 2] = 0.f;
+                }
+                if (A.skip_counter && tid == 0) atomicAdd(A.skip_counter, 1ull);
+                pipe_restart(P);
+                continue;
+            }
+        }
         if (FULL) hidden_layer<true>(Y, X, small + kBiasOff + 8 * 256, P, h); // bottleneck (no activation, :218)
 #endif
+#if NERF_LOOP_LAYERS
         if (valid && h == 0) A.sigma_out[i] = sigma;
+#endif
 
         if (FULL) {
             // direction encoding: 16 slots per lane-half (src/network.rs:294-330)

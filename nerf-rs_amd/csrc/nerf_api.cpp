@@ -56,6 +56,7 @@ struct nerf_ctx {
     float *d_out = nullptr; size_t out_floats = 0;       // host-pointer render output staging
     // scratch for forward_batch / stage calls
     void *d_scratch = nullptr; size_t scratch_bytes = 0;
+    unsigned long long *d_skip = nullptr;  // device counter of skipped 128-point tiles (skip_empty)
     unsigned long long *d_clock = nullptr; // diagnostic: per-workgroup {cycles, 100 MHz ticks} of the last fine-MLP launch
     bool clock_valid = false;
     size_t max_rays_per_pass = (size_t)1 << 20;
@@ -240,6 +241,8 @@ int render_device(nerf_ctx *c, const nerf_camera *cam, const nerf_render_opts *o
     for (int r : o->reserved) if (r != 0) return fail(c, NERF_ERR_INVALID, "reserved option fields must be 0");
     if (o->mlp_dtype != NERF_MLP_F32 && o->mlp_dtype != NERF_MLP_BF16) return fail(c, NERF_ERR_INVALID, "mlp_dtype must be NERF_MLP_F32 or NERF_MLP_BF16");
     const bool bf16 = o->mlp_dtype == NERF_MLP_BF16;
+    if (o->skip_empty != 0 && o->skip_empty != 1) return fail(c, NERF_ERR_INVALID, "skip_empty must be 0 or 1");
+    if (o->skip_empty && bf16) return fail(c, NERF_ERR_INVALID, "skip_empty is implemented for the f32 MLP only");
     if (!c->net[NERF_NET_COARSE].loaded) return fail(c, NERF_ERR_STATE, "coarse network not loaded");
     if (!o->coarse_only && !c->net[NERF_NET_FINE].loaded) return fail(c, NERF_ERR_STATE, "fine network not loaded");
     const int s = o->ssaa > 1 ? o->ssaa : 1;
@@ -267,6 +270,7 @@ int render_device(nerf_ctx *c, const nerf_camera *cam, const nerf_render_opts *o
     }
     recycle_render(c);
     recycle_dominant(c, 4096); // bound the backlog if the caller never queries
+    if (o->skip_empty && c->d_skip) HIP_TRY(c, hipMemsetAsync(c->d_skip, 0, sizeof(unsigned long long), st));
     const bool timing = true;
     RayGenArgs g = make_raygen(*cam, s);
     const DevNet &NC = c->net[NERF_NET_COARSE], &NF = c->net[NERF_NET_FINE];
@@ -289,6 +293,7 @@ int render_device(nerf_ctx *c, const nerf_camera *cam, const nerf_render_opts *o
         a.wstream = bf16 ? (const float *)NC.wstream_bf16 : NC.wstream; a.small_params = NC.small;
         a.n_points = n_rays * nc; a.samples_per_ray = nc; a.t = c->d_tc;
         a.sigma_out = c->d_sc; a.rgb_out = c->d_rgbc;
+        a.skip_empty = o->skip_empty; a.skip_counter = o->skip_empty ? c->d_skip : nullptr; // only full kernels look at it
         {
             Timed t(c, st, o->coarse_only ? 1 : 0, (uint64_t)a.n_points, timing);
             HIP_TRY(c, (bf16 ? nerf_mlp_bf16_launch : nerf_mlp_launch)(a, o->coarse_only != 0, c->n_cus, st));
@@ -360,6 +365,11 @@ int render_device(nerf_ctx *c, const nerf_camera *cam, const nerf_render_opts *o
             HIP_TRY(c, hipEventElapsedTime(&ms, c->last_render.front().a, c->last_render.back().b));
             stats->ms_total = ms;
         }
+        if (o->skip_empty && c->d_skip) {
+            unsigned long long tiles = 0;
+            HIP_TRY(c, hipMemcpy(&tiles, c->d_skip, sizeof tiles, hipMemcpyDeviceToHost));
+            stats->n_colour_skipped_points = (uint64_t)tiles * nerfmlp::kPointsPerBlock;
+        }
     }
     return NERF_OK;
 }
@@ -400,6 +410,7 @@ int nerf_create(int device_id, nerf_ctx **out) {
     if (const char *env = getenv("NERF_DEBUG_CLOCK")) {
         if (atoi(env) > 0 && hipMalloc((void **)&c->d_clock, (size_t)c->n_cus * 2 * sizeof(unsigned long long)) != hipSuccess) c->d_clock = nullptr;
     }
+    if (hipMalloc((void **)&c->d_skip, sizeof(unsigned long long)) != hipSuccess) c->d_skip = nullptr;
     hipError_t e1 = nerf_mlp_init();
     if (e1 == hipSuccess) e1 = nerf_mlp_bf16_init();
     hipError_t e2 = e1 == hipSuccess ? sampling_init() : e1;
@@ -422,6 +433,7 @@ void nerf_destroy(nerf_ctx *c) {
     for (float *p : ptrs) if (p) (void)hipFree(p);
     if (c->d_scratch) (void)hipFree(c->d_scratch);
     if (c->d_clock) (void)hipFree(c->d_clock);
+    if (c->d_skip) (void)hipFree(c->d_skip);
     recycle_render(c);
     recycle_dominant(c, 0);
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);

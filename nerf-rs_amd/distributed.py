@@ -15,7 +15,7 @@ def band_of_rank(n_rows, rank, world_size):
 
 
 def render_image_distributed(coarse, fine, camera, fine_samples_per_ray=128, *, seed=0, coarse_only=False, crop=None,
-                             ssaa=1, dtype="f32", group=None, band_renderer=None, device=None, return_tensor=False):
+                             ssaa=1, dtype="f32", skip_empty=False, group=None, band_renderer=None, device=None, return_tensor=False):
     """render_image over all ranks of `group` (torch.distributed; backend nccl == RCCL on ROCm, gloo in CPU tests).
 
     Every rank returns the full (h, w, 3) frame.  `band_renderer(crop) -> ndarray (rows, w, 3)` overrides the GPU
@@ -42,7 +42,7 @@ def render_image_distributed(coarse, fine, camera, fine_samples_per_ray=128, *, 
         if rows > 0:
             stream = torch.cuda.current_stream(dev).cuda_stream
             render_image(coarse, fine, camera, fine_samples_per_ray, seed=seed, coarse_only=coarse_only, crop=band_crop,
-                         ssaa=ssaa, dtype=dtype, device_out=band.data_ptr(), stream=stream)
+                         ssaa=ssaa, dtype=dtype, skip_empty=skip_empty, device_out=band.data_ptr(), stream=stream)
     gathered = torch.empty((world, max_rows, w, 3), dtype=torch.float32, device=band.device)
     dist.all_gather_into_tensor(gathered.view(-1), band.view(-1), group=group) if band.device.type == "cuda" else \
         dist.all_gather(list(gathered.unbind(0)), band, group=group)

@@ -467,3 +467,23 @@ def test_odd_sample_counts_and_large_batches(renderer, native, oracle, oracle_ne
     base_rgb, base_sg = renderer.fine.forward_batch(g["pts"], g["dirs"])
     assert np.array_equal(sg.reshape(reps, 4096), np.tile(base_sg, (reps, 1)))
     assert np.array_equal(rgb.reshape(reps, 4096, 3)[::97], np.tile(base_rgb, (reps, 1, 1))[::97])
+
+
+def test_skip_empty_is_bit_exact(renderer, native, samples):
+    """skip_empty: tiles whose 128 densities are all zero skip the colour head.  Their weights are exactly
+    0, so the image must be BIT-identical to the non-skipping render -- full frame, a crop, coarse-only, several passes."""
+    cam = native.camera_from_samples(samples, 800, 800, 64)
+    crop = (250, 300, 300, 120)
+    ref = native.render_image(renderer.coarse, renderer.fine, cam, 128, seed=0, crop=crop)
+    img, st = native.render_image(renderer.coarse, renderer.fine, cam, 128, seed=0, crop=crop, skip_empty=True, return_stats=True)
+    assert np.array_equal(img, ref)
+    assert 0.2 * st.n_fine_points < st.n_colour_skipped_points < st.n_fine_points   # it really skipped a lot, not everything
+    assert st.n_colour_skipped_points % 128 == 0
+    cam4 = native.camera_from_samples(samples, 400, 400, 64)
+    c_ref = native.render_image(renderer.coarse, renderer.fine, cam4, 0, seed=0, coarse_only=True, crop=(100, 100, 200, 120))
+    c_img = native.render_image(renderer.coarse, renderer.fine, cam4, 0, seed=0, coarse_only=True, crop=(100, 100, 200, 120), skip_empty=True)
+    assert np.array_equal(c_img, c_ref)
+    corner = native.render_image(renderer.coarse, renderer.fine, cam, 128, seed=3, crop=(0, 0, 64, 16), skip_empty=True)
+    assert np.all(corner == 1.0)                                # pure background: every tile skipped, still exactly white
+    with pytest.raises(native.NerfError):
+        native.render_image(renderer.coarse, renderer.fine, cam, 128, crop=crop, skip_empty=True, dtype="bf16")
