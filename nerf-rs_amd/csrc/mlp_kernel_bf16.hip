@@ -134,6 +134,25 @@ __device__ __forceinline__ void pipe_half(PipeB &P, int ms, int hf, bf16x8 (&a)[
     __builtin_amdgcn_sched_barrier(0);
 }
 
+// Bring the pipeline into the state a steady-state run is in when chunk 0 starts: chunk 0 landed; chunk 1 selected with
+// the four pieces macro-steps 2,3 of "chunk -1" would have issued (macro-steps 0,1 of chunk 0 issue its pieces 4..7);
+// operands of the first half macro-step fetched.  Called by every wave at the same point, after a workgroup barrier.
+__device__ __forceinline__ void pipe_start(PipeB &P) {
+    P.next_off = 0;
+    P.wr_slot_off = 0;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        pipe_next_chunk(P);
+#pragma unroll
+        for (int i = 0; i < (c < 1 ? 8 : 4); ++i) pipe_issue_piece(P, i);
+    }
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    P.rd_slot_off = 0;
+    P.rd_base = P.ring_lane;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) P.nx[j] = *(const LDS_AS bf16x8 *)(P.rd_base + j * 1024);
+}
+
 // The two DMA pieces of macro-step ms: pieces of the chunk selected at the last sync, in issue order
 // ms 2 -> 0,1   ms 3 -> 2,3   ms 0 -> 4,5   ms 1 -> 6,7.
 __device__ __forceinline__ void pipe_dma(PipeB &P, int ms, int k) {
@@ -322,24 +341,10 @@ __global__ __launch_bounds__(256, 1) void nerf_mlp_kernel_bf16(const MlpArgs A) 
     P.lane16 = lane16;
     P.ring_lane = lds + lane16;
     P.ring_addr = (uint32_t)(uintptr_t)lds + wave * 8192;
-    P.wr_slot_off = 0;
-    P.next_off = 0;
     P.stream_bytes = (FULL ? kChunksFullBf16 : kChunksSigmaBf16) * kCB;
     P.gbase = (const char *)A.wstream + wave * 8192;
     __syncthreads();
-    // prologue = the state a steady-state pipeline is in when chunk 0 starts: chunk 0 landed; chunk 1 selected with the
-    // four pieces macro-steps 2,3 of "chunk -1" would have issued (macro-steps 0,1 of chunk 0 issue its pieces 4..7).
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-        pipe_next_chunk(P);
-#pragma unroll
-        for (int i = 0; i < (c < 1 ? 8 : 4); ++i) pipe_issue_piece(P, i);
-    }
-    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-    P.rd_slot_off = 0;
-    P.rd_base = P.ring_lane;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) P.nx[j] = *(const LDS_AS bf16x8 *)(P.rd_base + j * 1024);
+    pipe_start(P);
 
     struct RawIn { float a, b, c, dx, dy, dz; };
     auto load_raw = [&](int tile_idx) -> RawIn {
@@ -409,6 +414,23 @@ __global__ __launch_bounds__(256, 1) void nerf_mlp_kernel_bf16(const MlpArgs A) 
 
         const float sigma = alpha_head(Y, small, h);
         if (valid && h == 0) A.sigma_out[i] = sigma;
+
+        if (FULL && A.skip_empty) { // exact empty-tile skip, see mlp_kernel.hip
+            LDS_AS int *vote = (LDS_AS int *)(lds + kRS * kCB) + kMiscOff + 8;
+            const bool any_wave = __any(valid && sigma > 0.0f);
+            if (lane == 0) vote[wave] = any_wave ? 1 : 0;
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            const int any_wg = vote[0] | vote[1] | vote[2] | vote[3];
+            if (!any_wg) {
+                if (valid && h == 0) {
+                    A.rgb_out[3 * (size_t)i + 0] = 0.f; A.rgb_out[3 * (size_t)i + 1] = 0.f; A.rgb_out[3 * (size_t)i + 2] = 0.f;
+                }
+                if (A.skip_counter && tid == 0) atomicAdd(A.skip_counter, 1ull);
+                asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory"); // in-flight chunks landed; ring idle
+                pipe_start(P);
+                continue;
+            }
+        }
 
         if (FULL) {
             hidden_layer<true>(Y, X, small + kBiasOff + 8 * 256, P, h); // bottleneck, no activation on its output

@@ -242,7 +242,6 @@ int render_device(nerf_ctx *c, const nerf_camera *cam, const nerf_render_opts *o
     if (o->mlp_dtype != NERF_MLP_F32 && o->mlp_dtype != NERF_MLP_BF16) return fail(c, NERF_ERR_INVALID, "mlp_dtype must be NERF_MLP_F32 or NERF_MLP_BF16");
     const bool bf16 = o->mlp_dtype == NERF_MLP_BF16;
     if (o->skip_empty != 0 && o->skip_empty != 1) return fail(c, NERF_ERR_INVALID, "skip_empty must be 0 or 1");
-    if (o->skip_empty && bf16) return fail(c, NERF_ERR_INVALID, "skip_empty is implemented for the f32 MLP only");
     if (!c->net[NERF_NET_COARSE].loaded) return fail(c, NERF_ERR_STATE, "coarse network not loaded");
     if (!o->coarse_only && !c->net[NERF_NET_FINE].loaded) return fail(c, NERF_ERR_STATE, "fine network not loaded");
     const int s = o->ssaa > 1 ? o->ssaa : 1;
