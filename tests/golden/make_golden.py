@@ -7,14 +7,14 @@ known-answer test in the reference, so these fixtures are produced BY the oracle
 src/lib.rs:176-565) and pin (a) the oracle against regressions and (b) the GPU path on the GPU box, where
 /root/reference does not exist.  Deterministic: counter-based RNG, seed recorded in each file.
 
-    python tools/make_golden.py            # rewrites tests/golden/
+    python tests/golden/make_golden.py     # rewrites tests/golden/
 """
 import os
 import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import oracle_py as O  # noqa: E402
 

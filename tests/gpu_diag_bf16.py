@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""bf16 MLP kernel: arithmetic check against the oracle's bf16 emulation + frame timing / PSNR gates."""
+"""Diagnostic script (not a pytest module; run by hand on the GPU box).  bf16 MLP kernel: arithmetic check against the oracle's bf16 emulation + frame timing / PSNR gates."""
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -1,4 +1,4 @@
-"""Oracle stage functions (a1-a3, a9-a14): regression against the committed fixtures (tools/make_golden.py) plus the
+"""Oracle stage functions (a1-a3, a9-a14): regression against the committed fixtures (tests/golden/make_golden.py) plus the
 semantic properties the reference's code implies (src/lib.rs:176-351).  No known-answer test exists for these in the
 reference -- the fixtures pin the restatement, not the reference."""
 import os
