@@ -160,6 +160,24 @@ def main():
                             skip_empty=True, device_out=frame.data_ptr(), stream=stream, return_stats=True)
         skipped_per_launch = st.n_colour_skipped_points
         r.kernel_time_query(reset=True)
+    # Reported separately, never part of `value`: the same frame with exact empty-tile skipping.
+    extra_skip = None
+    if world == 1 and not args.skip_empty:
+        def skip_step():
+            N.render_image(r.coarse, r.fine, cam, args.fine, seed=args.seed, ssaa=args.ssaa, dtype=args.dtype, skip_empty=True,
+                           device_out=frame.data_ptr(), stream=stream)
+        ref_frame = frame.clone()
+        skip_step(); torch.cuda.synchronize(dev)
+        identical = bool(torch.equal(frame, ref_frame))
+        t1 = time.perf_counter()
+        for _ in range(2):
+            skip_step()
+        torch.cuda.synchronize(dev)
+        ms = 1e3 * (time.perf_counter() - t1) / 2
+        extra_skip = {"rays_per_s": args.width * args.height * args.ssaa * args.ssaa / (ms * 1e-3), "ms_per_step": ms,
+                      "image_bit_identical_to_headline_run": identical,
+                      "note": "opt-in skip_empty: colour head skipped for 128-sample tiles whose densities are all 0 (exact)"}
+        r.kernel_time_query(reset=True)
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     if use_dist:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -193,6 +211,8 @@ def main():
                          "launches": n_dom, "avg_launch_ms": ms_dom / max(n_dom, 1),
                          "points_per_launch": pts_dom // max(n_dom, 1), "flop_per_point": N.FLOP_PER_POINT_FULL},
         }
+        if extra_skip:
+            line["extra_skip_empty"] = extra_skip
         if world == 1 and not args.no_cpu_baseline and not bf16:
             line["cpu_baseline"] = cpu_baseline(args.width, args.height, args.coarse, args.fine, args.seed, args.cpu_naive)
         print(json.dumps(line), flush=True)
