@@ -18,10 +18,12 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "mlp_common.hip.h"
 #include "mlp_kernel.h"
 #include "mlp_layout.h"
 
 using namespace nerfmlp;
+using namespace mlpdev;
 
 // Tuning switches (A/B-tested on MI355X).
 #ifndef NERF_DMA_SPREAD
@@ -44,9 +46,6 @@ using namespace nerfmlp;
 #define NERF_STR(x) NERF_STR2(x)
 // chunks allowed to stay in flight across the mid-chunk sync: kRingSlots - 3 (4 pieces each)
 #define NERF_SYNC_VMCNT ((NERF_RING_SLOTS - 3) * 4)
-#ifndef NERF_RELU_PIPE
-#define NERF_RELU_PIPE 0 // (measured slower, 89.0 % vs 92.3 %: interleaving VALU between MFMAs costs more than clustering it) 1: the next k-step's B operand (AGPR read + ReLU) is prepared between the current step's MFMAs
-#endif
 #ifndef NERF_RELU_GROUP
 #define NERF_RELU_GROUP 16 // (1: 92.1 %, 2: 93.4 %, 4: 94.1 %, 8: 94.3 %, 16: 94.4 % of the fp32 MFMA roofline) B operands (AGPR read + ReLU) are prepared for this many k-steps in ONE contiguous VALU burst
 #endif
@@ -56,17 +55,11 @@ using namespace nerfmlp;
 #ifndef NERF_PIN_CHAINS
 #define NERF_PIN_CHAINS 0 // 1: zero-instruction asm touching all accumulators after every input tile (keeps MFMA chains in program order)
 #endif
-#ifndef NERF_LOOP_LAYERS
-#define NERF_LOOP_LAYERS 0 // (measured slower: 87.1 % vs 87.8 %; kept for the record) 1: dense1..7 + bottleneck as a runtime loop over 4 layer pairs (instruction-cache resident)
-#endif
 #ifndef NERF_PREFETCH_INPUTS
 #define NERF_PREFETCH_INPUTS 1 // 1: the next tile's t / direction are loaded one tile ahead
 #endif
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-#define LDS_AS __attribute__((address_space(3)))
 
 namespace {
 
@@ -88,22 +81,6 @@ struct Pipe {
     uint32_t cur_dst;        // its LDS destination
     uint32_t lane16;
 };
-
-// One 1-KiB LDS-DMA piece (64 lanes x 16 B, lane-linear in LDS).  Hidden from the compiler's waitcnt bookkeeping on
-// purpose (it would drain vmcnt(0) in front of every later ds_read); completion is enforced by the explicit
-// vmcnt(0) + s_barrier in pipe_sync().  No instruction offset: the immediate of global_load_lds applies to the global
-// AND the LDS address.
-__device__ __forceinline__ void glds_piece(uint32_t lane16, const char *gsrc, uint32_t dst) {
-    uint32_t keep;
-    asm volatile("s_mov_b32 %0, m0\n\t"
-                 "s_mov_b32 m0, %3\n\t"
-                 "s_nop 0\n\t"
-                 "global_load_lds_dwordx4 %1, %2\n\t"
-                 "s_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(lane16), "s"(gsrc), "s"(dst)
-                 : "memory");
-}
 
 // Select the next chunk: its stream offset and ring slot (kept opaque so the 145 values are not constant-folded
 // into 145 live address registers).
@@ -212,14 +189,6 @@ __device__ __forceinline__ void pipe_advance(Pipe &P, int ms, f32x4 &a0, f32x4 &
     a1 = P.cu[2 * (ms % LG) + 1];
 }
 
-// ReLU as a signed-integer max on the bit pattern: one v_max_i32 (fmaxf costs an extra canonicalising v_max), and --
-// unlike inline asm -- visible to hipcc's hazard recogniser, which must pad the VALU-write -> MFMA-operand-read
-// wait states.  Negative floats and -0.0 are negative integers -> +0.0; positives are unchanged.
-__device__ __forceinline__ float relu(float v) {
-    const int b = __builtin_bit_cast(int, v);
-    return __builtin_bit_cast(float, b > 0 ? b : 0);
-}
-
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 
 // ---- one input tile (16 k-steps) of a layer with NT output tiles --------------------------------
@@ -228,56 +197,6 @@ __device__ __forceinline__ float relu(float v) {
 template <int NT, bool RELU>
 __device__ __forceinline__ void tile_steps(const f32x16 &in, f32x16 (&out)[NT], Pipe &P) {
     static_assert(NT == 8 || NT == 4, "NT");
-#if NERF_RELU_PIPE
-    // B operands are software-pipelined by one k-step: the dependent pair (v_accvgpr_read, v_max_i32) of step r+1 is
-    // split around the MFMAs of step r, so it costs two issue slots instead of two dependent-latency stalls + s_nop.
-    if constexpr (NT == 8) {
-        float b = RELU ? relu(in[0]) : in[0];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            f32x4 a0, a1;
-            if ((r & 7) == 4) pipe_sync(P);
-            pipe_advance(P, r & 7, a0, a1);
-            out[0] = MFMA(a0[0], b, out[0]); out[1] = MFMA(a0[1], b, out[1]);
-            pipe_mid_step(P, r & 7);
-            float raw = 0.f;
-            if (r < 15) { raw = in[r + 1]; asm volatile("" : "+v"(raw)); }
-            __builtin_amdgcn_sched_barrier(0);
-            out[2] = MFMA(a0[2], b, out[2]); out[3] = MFMA(a0[3], b, out[3]);
-            out[4] = MFMA(a1[0], b, out[4]);
-            __builtin_amdgcn_sched_barrier(0);
-            float bn = raw;
-            if (RELU) asm volatile("v_max_i32 %0, 0, %1" : "=v"(bn) : "v"(raw)); // consumer is >= 3 MFMAs away: no hazard
-            __builtin_amdgcn_sched_barrier(0);
-            out[5] = MFMA(a1[1], b, out[5]);
-            out[6] = MFMA(a1[2], b, out[6]); out[7] = MFMA(a1[3], b, out[7]);
-            b = bn;
-        }
-    } else {
-        float b0 = RELU ? relu(in[0]) : in[0];
-        float b1 = RELU ? relu(in[1]) : in[1];
-#pragma unroll
-        for (int r = 0; r < 16; r += 2) {
-            f32x4 a0, a1;
-            if (r / 2 == 4) pipe_sync(P);
-            pipe_advance(P, r / 2, a0, a1);
-            out[0] = MFMA(a0[0], b0, out[0]); out[1] = MFMA(a0[1], b0, out[1]);
-            pipe_mid_step(P, r / 2);
-            float r0 = 0.f, r1 = 0.f;
-            if (r < 14) { r0 = in[r + 2]; r1 = in[r + 3]; asm volatile("" : "+v"(r0), "+v"(r1)); }
-            __builtin_amdgcn_sched_barrier(0);
-            out[2] = MFMA(a0[2], b0, out[2]); out[3] = MFMA(a0[3], b0, out[3]);
-            out[0] = MFMA(a1[0], b1, out[0]);
-            __builtin_amdgcn_sched_barrier(0);
-            float n0 = r0, n1 = r1;
-            if (RELU) asm volatile("v_max_i32 %0, 0, %2\n\tv_max_i32 %1, 0, %3" : "=&v"(n0), "=v"(n1) : "v"(r0), "v"(r1));
-            __builtin_amdgcn_sched_barrier(0);
-            out[1] = MFMA(a1[1], b1, out[1]);
-            out[2] = MFMA(a1[2], b1, out[2]); out[3] = MFMA(a1[3], b1, out[3]);
-            b0 = n0; b1 = n1;
-        }
-    }
-#else
     // Every interruption of the fp32 MFMA stream by VALU work costs more than the VALU instructions themselves, so
     // the B operands of G consecutive k-steps are prepared in one burst (G more live VGPRs).
     constexpr int G = RELU ? NERF_RELU_GROUP : 1;
@@ -321,7 +240,6 @@ __device__ __forceinline__ void tile_steps(const f32x16 &in, f32x16 (&out)[NT], 
             out[2] = MFMA(a1[2], b1, out[2]); out[3] = MFMA(a1[3], b1, out[3]);
         }
     }
-#endif
 #if NERF_PIN_CHAINS
     if constexpr (NT == 8)
         asm volatile("" : "+a"(out[0]), "+a"(out[1]), "+a"(out[2]), "+a"(out[3]), "+a"(out[4]), "+a"(out[5]), "+a"(out[6]), "+a"(out[7]));
@@ -351,35 +269,6 @@ __device__ __forceinline__ void hidden_layer(const f32x16 (&in)[8], f32x16 (&out
 #pragma unroll
     for (int t = 0; t < 8; ++t) tile_steps<8, RELU>(in[t], out, P);
 }
-
-// sin and cos of x for |x| <= 2^11 (the encodings reach ~1.25e3 rad): k = rint(x * 2/pi), three-constant Cody-Waite
-// reduction with FMA (x - k*pi/2 is exact in the first step), Cephes sinf/cosf minimax polynomials on [-pi/4, pi/4],
-// quadrant fix-up by sign-bit arithmetic.  Branch-free; max error 1.6 ulp over the whole range (tools/check_sincos.py).
-__device__ __forceinline__ void fast_sincos(float x, float *s_out, float *c_out) {
-#if NERF_FAST_SINCOS
-    const float k = __builtin_rintf(x * 0.636619772f);
-    float r = fmaf(k, -1.5707963705062866f, x);
-    r = fmaf(k, 4.371138828673793e-08f, r);
-    r = fmaf(k, 1.7763568394002505e-15f, r);
-    const float r2 = r * r;
-    float ps = fmaf(r2, -1.9515295891e-4f, 8.3321608736e-3f);
-    ps = fmaf(r2, ps, -1.6666654611e-1f);
-    const float s = fmaf(r * r2, ps, r);
-    float pc = fmaf(r2, 2.443315711809948e-5f, -1.388731625493765e-3f);
-    pc = fmaf(r2, pc, 4.166664568298827e-2f);
-    const float c = fmaf(r2 * r2, pc, fmaf(r2, -0.5f, 1.0f));
-    const uint32_t q = (uint32_t)(int)k;
-    const bool swap = (q & 1u) != 0;
-    const uint32_t sb = __builtin_bit_cast(uint32_t, swap ? c : s) ^ ((q & 2u) << 30);
-    const uint32_t cb = __builtin_bit_cast(uint32_t, swap ? s : c) ^ (((q + 1u) & 2u) << 30);
-    *s_out = __builtin_bit_cast(float, sb);
-    *c_out = __builtin_bit_cast(float, cb);
-#else
-    sincosf(x, s_out, c_out);
-#endif
-}
-
-__device__ __forceinline__ float xhalf_sum(float v) { return v + __shfl_xor(v, 32, 64); }
 
 // alpha head on the VALU: sigma = relu(b + sum_F w[F] relu(h8[F]))  (src/network.rs:216)
 __device__ __forceinline__ float alpha_head(const f32x16 (&Y)[8], const LDS_AS float *small, int h) {
@@ -442,64 +331,25 @@ __global__ __launch_bounds__(256, 1) void nerf_mlp_kernel(const MlpArgs A) {
         P.nx[2 * j + 1] = *(const LDS_AS f32x4 *)(P.rd_base + j * 2048 + 1024);
     }
 
-    // Raw per-point inputs: 6 floats.  MODE_POINTS: position + direction as given (src/network.rs:197).
-    // MODE_RAYS: (t, unused, unused) + the ray's unit direction; p = origin + dir_hat * t is formed at use with the
-    // multiply and the add rounded separately (src/lib.rs:396 / :436).
-    struct RawIn { float a, b, c, dx, dy, dz; };
-    auto load_raw = [&](int tile_idx) -> RawIn {
-        RawIn r;
-        int i = tile_idx * kPointsPerBlock + wave * kPointsPerWave + p;
-        i = i < A.n_points ? i : A.n_points - 1; // clamp: the padding lanes of the last tile and the look-ahead tile
-        if (MODE == MLP_MODE_POINTS) {
-            r.a = A.pts_soa[i]; r.b = A.pts_soa[(size_t)A.n_points + i]; r.c = A.pts_soa[2 * (size_t)A.n_points + i];
-            r.dx = A.dirs_aos[3 * (size_t)i]; r.dy = A.dirs_aos[3 * (size_t)i + 1]; r.dz = A.dirs_aos[3 * (size_t)i + 2];
-        } else {
-            const int ray = i / A.samples_per_ray;
-            r.a = A.t[i]; r.b = 0.f; r.c = 0.f;
-            r.dx = A.ray_dirs[3 * (size_t)ray]; r.dy = A.ray_dirs[3 * (size_t)ray + 1]; r.dz = A.ray_dirs[3 * (size_t)ray + 2];
-        }
-        return r;
-    };
-
     const int n_tiles = (A.n_points + kPointsPerBlock - 1) / kPointsPerBlock;
 #if NERF_PREFETCH_INPUTS
-    RawIn nxt = load_raw(blockIdx.x);
+    RawIn nxt = load_raw<MODE>(A, blockIdx.x, wave, p);
 #endif
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const int i = tile * kPointsPerBlock + wave * kPointsPerWave + p;
         const bool valid = i < A.n_points;
 #if NERF_PREFETCH_INPUTS
         const RawIn in = nxt;
-        nxt = load_raw(tile + gridDim.x); // consumed one tile (~250 us) later
+        nxt = load_raw<MODE>(A, tile + gridDim.x, wave, p); // consumed one tile (~250 us) later
 #else
-        const RawIn in = load_raw(tile);
+        const RawIn in = load_raw<MODE>(A, tile, wave, p);
 #endif
         float px, py, pz;
+        point_of<MODE>(A, in, px, py, pz);
         const float dx = in.dx, dy = in.dy, dz = in.dz;
-        if (MODE == MLP_MODE_POINTS) {
-            px = in.a; py = in.b; pz = in.c;
-        } else {
-            px = __fadd_rn(A.origin[0], __fmul_rn(dx, in.a));
-            py = __fadd_rn(A.origin[1], __fmul_rn(dy, in.a));
-            pz = __fadd_rn(A.origin[2], __fmul_rn(dz, in.a));
-        }
 
-        // ---- positional encoding of the point: this lane-half's 32 slots (src/network.rs:263-292)
         f32x16 E[2];
-        {
-            const float f0 = h ? 32.0f : 1.0f; // octaves 5h .. 5h+4
-            float f = f0;
-#pragma unroll
-            for (int o = 0; o < 5; ++o) {
-                float s, c;
-                fast_sincos(f * px, &s, &c); E[(6 * o + 0) >> 4][(6 * o + 0) & 15] = s; E[(6 * o + 3) >> 4][(6 * o + 3) & 15] = c;
-                fast_sincos(f * py, &s, &c); E[(6 * o + 1) >> 4][(6 * o + 1) & 15] = s; E[(6 * o + 4) >> 4][(6 * o + 4) & 15] = c;
-                fast_sincos(f * pz, &s, &c); E[(6 * o + 2) >> 4][(6 * o + 2) & 15] = s; E[(6 * o + 5) >> 4][(6 * o + 5) & 15] = c;
-                f *= 2.0f;
-            }
-            E[1][14] = h ? pz : px;
-            E[1][15] = h ? 0.0f : py;
-        }
+        encode_point<NERF_FAST_SINCOS != 0>(px, py, pz, h, E);
 
         f32x16 X[8], Y[8];
 
@@ -509,30 +359,6 @@ __global__ __launch_bounds__(256, 1) void nerf_mlp_kernel(const MlpArgs A) {
         tile_steps<8, false>(E[1], X, P);
 
         float sigma = 0.f;
-#if NERF_LOOP_LAYERS
-        // dense1..dense7 + bottleneck as FOUR passes over one pair of layer bodies (X -> Y, Y -> X).  The straight-line
-        // form of the network is ~270 KB of code per tile, four times the 64 KB instruction cache, and ran ~6 cycles
-        // per MFMA slower than the same stream looped; the loop body (~48 KB) stays cache-resident.
-        //   p = 0: dense1, dense2   p = 1: dense3, dense4   p = 2: dense5 (skip: encoding steps first), dense6
-        //   p = 3: dense7, [alpha head], bottleneck (full kernels only)
-#pragma nounroll
-        for (int p2 = 0; p2 < 4; ++p2) {
-            load_bias<8>(Y, small + kBiasOff + (1 + 2 * p2) * 256, h);
-            if (p2 == 2) { // dense5 = [encoding ; h4] (src/network.rs:209-210): the 32 encoding k-steps come first
-                tile_steps<8, false>(E[0], Y, P);
-                tile_steps<8, false>(E[1], Y, P);
-            }
-#pragma unroll
-            for (int t = 0; t < 8; ++t) tile_steps<8, true>(X[t], Y, P);
-            if (p2 == 3) {
-                sigma = alpha_head(Y, small, h);
-                if (!FULL) break;
-            }
-            load_bias<8>(X, small + kBiasOff + (2 + 2 * p2) * 256, h); // p2 == 3: bottleneck (no activation, :218)
-#pragma unroll
-            for (int t = 0; t < 8; ++t) tile_steps<8, true>(Y[t], X, P);
-        }
-#else
         // dense1..4
         hidden_layer<true>(X, Y, small + kBiasOff + 1 * 256, P, h);
         hidden_layer<true>(Y, X, small + kBiasOff + 2 * 256, P, h);
@@ -554,10 +380,7 @@ __global__ __launch_bounds__(256, 1) void nerf_mlp_kernel(const MlpArgs A) {
             // alpha = 1 - exp(-0 * delta) = 0 and w = T * 0 = 0 exactly for each of them (src/lib.rs:271-272), so their
             // colours never reach a pixel: skip bottleneck + viewdirs + rgb (17 % of a full evaluation), write rgb = 0.
             LDS_AS int *vote = (LDS_AS int *)(lds + kRingSlots * kChunkBytes) + kMiscOff + 8;
-            const bool any_wave = __any(valid && sigma > 0.0f);
-            if (lane == 0) vote[wave] = any_wave ? 1 : 0;
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            const int any_wg = vote[0] | vote[1] | vote[2] | vote[3];
+            const bool any_wg = tile_has_density(vote, valid && sigma > 0.0f, wave, lane);
             if (!any_wg) {
                 if (valid && h == 0) {
                     A.rgb_out[3 * (size_t)i + 0] = 0.f; A.rgb_out[3 * (size_t)i + 1] = 0.f; A.rgb_out[3 * (size_t)i + 2] = 0.f;
@@ -568,52 +391,18 @@ __global__ __launch_bounds__(256, 1) void nerf_mlp_kernel(const MlpArgs A) {
             }
         }
         if (FULL) hidden_layer<true>(Y, X, small + kBiasOff + 8 * 256, P, h); // bottleneck (no activation, :218)
-#endif
-#if NERF_LOOP_LAYERS
-        if (valid && h == 0) A.sigma_out[i] = sigma;
-#endif
 
         if (FULL) {
-            // direction encoding: 16 slots per lane-half (src/network.rs:294-330)
             f32x16 D;
-            {
-                float f = h ? 4.0f : 1.0f; // octaves 2h, 2h+1
-#pragma unroll
-                for (int o = 0; o < 2; ++o) {
-                    float s, c;
-                    fast_sincos(f * dx, &s, &c); D[6 * o + 0] = s; D[6 * o + 3] = c;
-                    fast_sincos(f * dy, &s, &c); D[6 * o + 1] = s; D[6 * o + 4] = c;
-                    fast_sincos(f * dz, &s, &c); D[6 * o + 2] = s; D[6 * o + 5] = c;
-                    f *= 2.0f;
-                }
-                D[12] = h ? 0.f : dx; D[13] = h ? 0.f : dy; D[14] = h ? 0.f : dz; D[15] = 0.f;
-            }
+            encode_dir<NERF_FAST_SINCOS != 0>(dx, dy, dz, h, D);
             // viewdirs: [bottleneck ; dir encoding] -> 128 (src/network.rs:219-222)
             f32x16 V[4];
             load_bias<4>(V, small + kBiasViewOff, h);
 #pragma unroll
             for (int t = 0; t < 8; ++t) tile_steps<4, false>(X[t], V, P);
             tile_steps<4, false>(D, V, P);
-            // rgb head on the VALU + sigmoid (src/network.rs:223, :165)
             float c[3];
-#pragma unroll
-            for (int ch = 0; ch < 3; ++ch) {
-                const LDS_AS f32x4 *w = (const LDS_AS f32x4 *)(small + kRgbWOff + (h * 3 + ch) * 64);
-                float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const f32x4 wv = w[t * 4 + q];
-                        a0 = fmaf(wv[0], relu(V[t][4 * q + 0]), a0);
-                        a1 = fmaf(wv[1], relu(V[t][4 * q + 1]), a1);
-                        a2 = fmaf(wv[2], relu(V[t][4 * q + 2]), a2);
-                        a3 = fmaf(wv[3], relu(V[t][4 * q + 3]), a3);
-                    }
-                }
-                const float v = xhalf_sum((a0 + a1) + (a2 + a3)) + small[kMiscOff + 1 + ch];
-                c[ch] = 1.0f / (1.0f + expf(-v));
-            }
+            rgb_head(V, small, h, c);
             if (valid && h == 0) {
                 A.rgb_out[3 * (size_t)i + 0] = c[0];
                 A.rgb_out[3 * (size_t)i + 1] = c[1];

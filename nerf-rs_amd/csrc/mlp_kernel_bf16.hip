@@ -19,10 +19,12 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "mlp_common.hip.h"
 #include "mlp_kernel.h"
 #include "mlp_layout.h"
 
 using namespace nerfmlp;
+using namespace mlpdev;
 
 // Timing-only diagnostics (results are WRONG with any of these set; never shipped)
 #ifndef NERF_BDIAG_NO_BARRIER
@@ -38,13 +40,9 @@ using namespace nerfmlp;
 #define NERF_BDIAG_NO_BPREP 0
 #endif
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 
-#define LDS_AS __attribute__((address_space(3)))
 
 namespace {
 
@@ -64,18 +62,6 @@ struct PipeB {
     uint32_t cur_dst;
     uint32_t lane16;
 };
-
-__device__ __forceinline__ void glds_piece(uint32_t lane16, const char *gsrc, uint32_t dst) {
-    uint32_t keep;
-    asm volatile("s_mov_b32 %0, m0\n\t"
-                 "s_mov_b32 m0, %3\n\t"
-                 "s_nop 0\n\t"
-                 "global_load_lds_dwordx4 %1, %2\n\t"
-                 "s_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(lane16), "s"(gsrc), "s"(dst)
-                 : "memory");
-}
 
 __device__ __forceinline__ void pipe_next_chunk(PipeB &P) {
     uint32_t off = P.next_off, slot = P.wr_slot_off;
@@ -160,11 +146,6 @@ __device__ __forceinline__ void pipe_dma(PipeB &P, int ms, int k) {
     __builtin_amdgcn_sched_barrier(0);
     pipe_issue_piece(P, base + k);
     __builtin_amdgcn_sched_barrier(0);
-}
-
-__device__ __forceinline__ float relu(float v) {
-    const int b = __builtin_bit_cast(int, v);
-    return __builtin_bit_cast(float, b > 0 ? b : 0);
 }
 
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
@@ -274,28 +255,6 @@ __device__ __forceinline__ void hidden_layer(f32x16 (&in)[8], f32x16 (&out)[8], 
     tile_steps<8, RELU, 0>(in[6], out, P); tile_steps<8, RELU, 2>(in[7], out, P);
 }
 
-__device__ __forceinline__ void fast_sincos(float x, float *s_out, float *c_out) { // see mlp_kernel.hip
-    const float k = __builtin_rintf(x * 0.636619772f);
-    float r = fmaf(k, -1.5707963705062866f, x);
-    r = fmaf(k, 4.371138828673793e-08f, r);
-    r = fmaf(k, 1.7763568394002505e-15f, r);
-    const float r2 = r * r;
-    float ps = fmaf(r2, -1.9515295891e-4f, 8.3321608736e-3f);
-    ps = fmaf(r2, ps, -1.6666654611e-1f);
-    const float s = fmaf(r * r2, ps, r);
-    float pc = fmaf(r2, 2.443315711809948e-5f, -1.388731625493765e-3f);
-    pc = fmaf(r2, pc, 4.166664568298827e-2f);
-    const float c = fmaf(r2 * r2, pc, fmaf(r2, -0.5f, 1.0f));
-    const uint32_t q = (uint32_t)(int)k;
-    const bool swap = (q & 1u) != 0;
-    const uint32_t sb = __builtin_bit_cast(uint32_t, swap ? c : s) ^ ((q & 2u) << 30);
-    const uint32_t cb = __builtin_bit_cast(uint32_t, swap ? s : c) ^ (((q + 1u) & 2u) << 30);
-    *s_out = __builtin_bit_cast(float, sb);
-    *c_out = __builtin_bit_cast(float, cb);
-}
-
-__device__ __forceinline__ float xhalf_sum(float v) { return v + __shfl_xor(v, 32, 64); }
-
 // alpha head on the VALU (f32): sigma = relu(b + sum_F w[F] relu(h8[F])).  The reads of each accumulator tile are pinned
 // (empty asm volatile) so that hipcc does not hoist all 128 AGPR reads at once (spills next to the 64 A-operand VGPRs).
 __device__ __forceinline__ float alpha_head(const f32x16 (&Y)[8], const LDS_AS float *small, int h) {
@@ -346,53 +305,19 @@ __global__ __launch_bounds__(256, 1) void nerf_mlp_kernel_bf16(const MlpArgs A) 
     __syncthreads();
     pipe_start(P);
 
-    struct RawIn { float a, b, c, dx, dy, dz; };
-    auto load_raw = [&](int tile_idx) -> RawIn {
-        RawIn r;
-        int i = tile_idx * kPointsPerBlock + wave * kPointsPerWave + p;
-        i = i < A.n_points ? i : A.n_points - 1;
-        if (MODE == MLP_MODE_POINTS) {
-            r.a = A.pts_soa[i]; r.b = A.pts_soa[(size_t)A.n_points + i]; r.c = A.pts_soa[2 * (size_t)A.n_points + i];
-            r.dx = A.dirs_aos[3 * (size_t)i]; r.dy = A.dirs_aos[3 * (size_t)i + 1]; r.dz = A.dirs_aos[3 * (size_t)i + 2];
-        } else {
-            const int ray = i / A.samples_per_ray;
-            r.a = A.t[i]; r.b = 0.f; r.c = 0.f;
-            r.dx = A.ray_dirs[3 * (size_t)ray]; r.dy = A.ray_dirs[3 * (size_t)ray + 1]; r.dz = A.ray_dirs[3 * (size_t)ray + 2];
-        }
-        return r;
-    };
-
     const int n_tiles = (A.n_points + kPointsPerBlock - 1) / kPointsPerBlock;
-    RawIn nxt = load_raw(blockIdx.x);
+    RawIn nxt = load_raw<MODE>(A, blockIdx.x, wave, p);
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const int i = tile * kPointsPerBlock + wave * kPointsPerWave + p;
         const bool valid = i < A.n_points;
         const RawIn in = nxt;
-        nxt = load_raw(tile + gridDim.x);
+        nxt = load_raw<MODE>(A, tile + gridDim.x, wave, p);
         float px, py, pz;
+        point_of<MODE>(A, in, px, py, pz);
         const float dx = in.dx, dy = in.dy, dz = in.dz;
-        if (MODE == MLP_MODE_POINTS) {
-            px = in.a; py = in.b; pz = in.c;
-        } else {
-            px = __fadd_rn(A.origin[0], __fmul_rn(dx, in.a));
-            py = __fadd_rn(A.origin[1], __fmul_rn(dy, in.a));
-            pz = __fadd_rn(A.origin[2], __fmul_rn(dz, in.a));
-        }
 
         f32x16 E[2];
-        {
-            float f = h ? 32.0f : 1.0f;
-#pragma unroll
-            for (int o = 0; o < 5; ++o) {
-                float s, c;
-                fast_sincos(f * px, &s, &c); E[(6 * o + 0) >> 4][(6 * o + 0) & 15] = s; E[(6 * o + 3) >> 4][(6 * o + 3) & 15] = c;
-                fast_sincos(f * py, &s, &c); E[(6 * o + 1) >> 4][(6 * o + 1) & 15] = s; E[(6 * o + 4) >> 4][(6 * o + 4) & 15] = c;
-                fast_sincos(f * pz, &s, &c); E[(6 * o + 2) >> 4][(6 * o + 2) & 15] = s; E[(6 * o + 5) >> 4][(6 * o + 5) & 15] = c;
-                f *= 2.0f;
-            }
-            E[1][14] = h ? pz : px;
-            E[1][15] = h ? 0.0f : py;
-        }
+        encode_point<true>(px, py, pz, h, E);
 
         f32x16 X[8], Y[8];
         load_bias<8>(X, small + kBiasOff + 0 * 256, h);
@@ -417,10 +342,7 @@ __global__ __launch_bounds__(256, 1) void nerf_mlp_kernel_bf16(const MlpArgs A) 
 
         if (FULL && A.skip_empty) { // exact empty-tile skip, see mlp_kernel.hip
             LDS_AS int *vote = (LDS_AS int *)(lds + kRS * kCB) + kMiscOff + 8;
-            const bool any_wave = __any(valid && sigma > 0.0f);
-            if (lane == 0) vote[wave] = any_wave ? 1 : 0;
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            const int any_wg = vote[0] | vote[1] | vote[2] | vote[3];
+            const bool any_wg = tile_has_density(vote, valid && sigma > 0.0f, wave, lane);
             if (!any_wg) {
                 if (valid && h == 0) {
                     A.rgb_out[3 * (size_t)i + 0] = 0.f; A.rgb_out[3 * (size_t)i + 1] = 0.f; A.rgb_out[3 * (size_t)i + 2] = 0.f;
@@ -435,18 +357,7 @@ __global__ __launch_bounds__(256, 1) void nerf_mlp_kernel_bf16(const MlpArgs A) 
         if (FULL) {
             hidden_layer<true>(Y, X, small + kBiasOff + 8 * 256, P, h); // bottleneck, no activation on its output
             f32x16 D;
-            {
-                float f = h ? 4.0f : 1.0f;
-#pragma unroll
-                for (int o = 0; o < 2; ++o) {
-                    float s, c;
-                    fast_sincos(f * dx, &s, &c); D[6 * o + 0] = s; D[6 * o + 3] = c;
-                    fast_sincos(f * dy, &s, &c); D[6 * o + 1] = s; D[6 * o + 4] = c;
-                    fast_sincos(f * dz, &s, &c); D[6 * o + 2] = s; D[6 * o + 5] = c;
-                    f *= 2.0f;
-                }
-                D[12] = h ? 0.f : dx; D[13] = h ? 0.f : dy; D[14] = h ? 0.f : dz; D[15] = 0.f;
-            }
+            encode_dir<true>(dx, dy, dz, h, D);
             // viewdirs accumulates into Y[0..3]: Y is dead after the bottleneck, and saying so explicitly keeps hipcc
             // from allocating a third accumulator set (which spilled 130 VGPRs)
             f32x16 (&V)[8] = Y;
@@ -458,24 +369,7 @@ __global__ __launch_bounds__(256, 1) void nerf_mlp_kernel_bf16(const MlpArgs A) 
             tile_steps<4, false, 0, false>(D, V, P);
             skip_macro_step<1>(P); skip_macro_step<2>(P); skip_macro_step<3>(P); // stream padding to the chunk end
             float c[3];
-#pragma unroll
-            for (int ch = 0; ch < 3; ++ch) {
-                const LDS_AS f32x4 *w = (const LDS_AS f32x4 *)(small + kRgbWOff + (h * 3 + ch) * 64);
-                float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const f32x4 wv = w[t * 4 + q];
-                        a0 = fmaf(wv[0], relu(V[t][4 * q + 0]), a0);
-                        a1 = fmaf(wv[1], relu(V[t][4 * q + 1]), a1);
-                        a2 = fmaf(wv[2], relu(V[t][4 * q + 2]), a2);
-                        a3 = fmaf(wv[3], relu(V[t][4 * q + 3]), a3);
-                    }
-                }
-                const float v = xhalf_sum((a0 + a1) + (a2 + a3)) + small[kMiscOff + 1 + ch];
-                c[ch] = 1.0f / (1.0f + expf(-v));
-            }
+            rgb_head(V, small, h, c);
             if (valid && h == 0) {
                 A.rgb_out[3 * (size_t)i + 0] = c[0];
                 A.rgb_out[3 * (size_t)i + 1] = c[1];
