@@ -115,8 +115,12 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU with torch.distributed.run")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    n_visible = torch.cuda.device_count()
+    if n_visible < 1:
+        raise SystemExit("bench.py needs an MI355X: no HIP device is visible (there is no CPU fallback)")
+    dev_index = local_rank % n_visible  # a launcher may expose one device per rank (then every rank uses index 0)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     # NERF_BENCH_FORCE_DIST=1 drives the N > 1 code path (process group, band split, RCCL all-gather) at world size 1
     use_dist = world > 1 or os.environ.get("NERF_BENCH_FORCE_DIST") == "1"
     if use_dist:
@@ -125,7 +129,7 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)  # nccl == RCCL on ROCm
 
     scene = os.path.join(ROOT, "lego_rust")
-    r = N.Renderer(local_rank)
+    r = N.Renderer(dev_index)
     r.load_scene(scene)
     cam = N.camera_from_samples(os.path.join(scene, "tf_reference_samples.json"), args.width, args.height, args.coarse)
     stream = torch.cuda.current_stream(dev).cuda_stream
