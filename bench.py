@@ -102,6 +102,7 @@ def main():
     ap.add_argument("--skip-empty", action="store_true",
                     help="SURVEY 8f.2 (reported separately, not the headline): skip the colour head of all-empty tiles; "
                          "the image is bit-identical, the roofline line then prices EXECUTED flops")
+    ap.add_argument("--no-extra", action="store_true", help="skip the separately reported skip_empty frames (profiling runs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-naive", action="store_true", help="also time the reference's own loop order (minutes)")
     args = ap.parse_args()
@@ -166,7 +167,7 @@ def main():
         r.kernel_time_query(reset=True)
     # Reported separately, never part of `value`: the same frame with exact empty-tile skipping.
     extra_skip = None
-    if world == 1 and not args.skip_empty:
+    if world == 1 and not args.skip_empty and not args.no_extra:
         def skip_step():
             N.render_image(r.coarse, r.fine, cam, args.fine, seed=args.seed, ssaa=args.ssaa, dtype=args.dtype, skip_empty=True,
                            device_out=frame.data_ptr(), stream=stream)

@@ -27,8 +27,8 @@ with open(os.path.join(dst, f"{tag}_pmc_summary.csv"), "w") as out:
     out.write("kernel,dispatches,ms_under_pmc," + ",".join(names) + "\n")
     for k, v in agg.items():
         out.write(f"\"{k}\",{calls[k]},{dur[k]:.3f}," + ",".join(f"{v.get(n, 0):.6g}" for n in names) + "\n")
-lines = [f"# rocprofv3 summary {tag}", "", "Command: `rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline` and",
-         "separate `--pmc` passes (`bench.py --steps 1 --warmup 0`), MI355X, 800x800, 64+128 samples.", "", "## kernel-trace stats", "", "```"]
+lines = [f"# rocprofv3 summary {tag}", "", "Command: `rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extra` and",
+         "separate `--pmc` passes (`bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extra`), MI355X, 800x800, 64+128 samples.", "", "## kernel-trace stats", "", "```"]
 lines += open(os.path.join(dst, f"{tag}_kernel_stats.csv")).read().strip().split("\n") + ["```", "", "## derived (PMC pass, one frame)", ""]
 for k, v in agg.items():
     if "nerf_mlp_kernel" not in k or not v.get("SQ_VALU_MFMA_BUSY_CYCLES"):
