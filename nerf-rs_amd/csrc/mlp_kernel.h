@@ -32,3 +32,6 @@ hipError_t nerf_mlp_launch(const MlpArgs &a, bool full, int n_blocks, hipStream_
 // bf16-operand variant (mlp_kernel_bf16.hip): a.wstream is the bf16 stream of pack_network_bf16
 hipError_t nerf_mlp_bf16_init();
 hipError_t nerf_mlp_bf16_launch(const MlpArgs &a, bool full, int n_blocks, hipStream_t stream);
+// second bf16 design (mlp_kernel_bf16v2.hip): a.wstream is the output-tile-major stream (mlp_layout.h kChunks*Bf16V2)
+hipError_t nerf_mlp_bf16v2_init();
+hipError_t nerf_mlp_bf16v2_launch(const MlpArgs &a, bool full, int n_blocks, hipStream_t stream);

@@ -1,0 +1,486 @@
+// mlp_kernel_bf16v2.hip -- bf16 MLP, output-tile-major, 64 points per wave (BASELINE config C5 study, second design).
+//
+// mlp_kernel_bf16.hip (v1) mirrors the f32 kernel: k-outer loop, all 8 accumulator tiles of a layer live, 32 points per
+// wave.  At bf16 MFMA rates that design is bound by operand delivery: every A fragment (one ds_read_b128, 1 KiB of
+// LDS-DMA per four waves) feeds ONE MFMA.  This kernel turns the loop nest around:
+//   for each output tile nt:  acc{0,1} = bias;  for each k-step ks:  A = piece(nt, ks);  acc0 += A x B0[ks];  acc1 += A x B1[ks]
+// * a wave owns 64 points = two 32-point sub-tiles; each A fragment feeds TWO MFMAs (half the LDS reads and half the
+//   LDS-DMA per point; a workgroup covers 256 points per pass over the weight stream);
+// * only 2 x 2 accumulator tiles are live (current + the one being converted); the layer's inputs and outputs are
+//   bf16-PACKED registers (4 VGPRs per k-step and sub-tile): a finished f32 accumulator tile, ReLU'd and converted pairwise
+//   (v_cvt_pk_bf16_f32 + v_pk_max_i16), IS k-steps 2 nt and 2 nt + 1 of the next layer (same k-permutation as v1: element j
+//   of lane-half h of k-step s of a tile = the tile's register 8 s + j = feature regFeature(8 s + j, h));
+// * the conversion of tile nt - 1 is interleaved, pair by pair, under the MFMAs of tile nt;
+// * alpha (dense7) and rgb (viewdirs) heads accumulate in f32 from the f32 accumulators inside those epilogues, so the
+//   arithmetic is exactly v1's (and the oracle emulation's): bf16 operands, f32 accumulate, f32 heads.
+// Weight stream (host_util.cpp pack_network_bf16_v2): per layer, per output tile, per k-step one 1-KiB piece; 16-KiB chunks
+// of 16 pieces; 60 chunks for the sigma layers, 73 for all (viewdirs' 72 pieces zero-padded to 80); 3-slot ring; sync at
+// piece 8 of every chunk; each wave DMA's one piece at pieces 9, 11, 13, 15.  All layers start at chunk boundaries.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <type_traits>
+
+#include "mlp_common.hip.h"
+#include "mlp_kernel.h"
+#include "mlp_layout.h"
+
+using namespace nerfmlp;
+using namespace mlpdev;
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+#ifndef NERF_BV2_SCHED_BARRIER
+#define NERF_BV2_SCHED_BARRIER 1 // keep the written interleave (A-operand prefetch distance, epilogue pairs between MFMA pairs)
+#endif
+#ifndef NERF_BV2_PREFETCH_INPUTS
+#define NERF_BV2_PREFETCH_INPUTS 1 // load the next tile's raw inputs one tile ahead
+#endif
+#ifndef NERF_BV2_DMA_INST_OFFSET
+#define NERF_BV2_DMA_INST_OFFSET 1 // one scalar base + M0 per chunk quarter, pieces addressed by the instruction offset
+#endif
+#ifndef NERF_BV2_AHEAD
+#define NERF_BV2_AHEAD 4
+#endif
+// timing-only diagnostics (results are garbage): which resource bounds the kernel
+#ifndef NERF_BV2_DIAG_NO_DMA
+#define NERF_BV2_DIAG_NO_DMA 0
+#endif
+#ifndef NERF_BV2_DIAG_NO_BARRIER
+#define NERF_BV2_DIAG_NO_BARRIER 0
+#endif
+#ifndef NERF_BV2_DIAG_NO_EPILOGUE
+#define NERF_BV2_DIAG_NO_EPILOGUE 0
+#endif
+#ifndef NERF_BV2_DIAG_NO_LDS
+#define NERF_BV2_DIAG_NO_LDS 0
+#endif
+
+namespace {
+
+constexpr int kCB = kChunkBytesBf16V2, kRS = kRingSlotsBf16V2;
+constexpr int kAhead = NERF_BV2_AHEAD; // A-operand prefetch distance in pieces
+
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F &&f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+struct PipeV {
+    const LDS_AS char *rd_base;   // LDS address (incl. lane * 16) of the chunk the next prefetched piece lives in
+    const LDS_AS char *ring_lane;
+    uint32_t rd_slot_off;
+    u32x4 a[kAhead];              // prefetched A operands of the next kAhead pieces
+    uint32_t ring_addr, wr_slot_off, next_off, stream_bytes;
+    const char *gbase, *cur_src;
+    uint32_t cur_dst, lane16;
+};
+
+__device__ __forceinline__ void pipe_next_chunk(PipeV &P) {
+    uint32_t off = P.next_off, slot = P.wr_slot_off;
+    asm volatile("" : "+s"(off), "+s"(slot));
+    P.cur_src = P.gbase + off;
+    P.cur_dst = P.ring_addr + slot;
+    off += kCB;
+    P.next_off = (off == P.stream_bytes) ? 0u : off;
+    slot += kCB;
+    P.wr_slot_off = (slot == kRS * kCB) ? 0u : slot;
+}
+
+// (Re)start at chunk 0: chunks 0 .. kRS - 2 loaded and visible, the first kAhead A operands prefetched.  The caller guarantees
+// that no wave still reads the ring (kernel start, or after a drain + barrier).
+__device__ __forceinline__ void pipe_start(PipeV &P) {
+    P.next_off = 0;
+    P.wr_slot_off = 0;
+#pragma unroll
+    for (int c = 0; c < kRS - 1; ++c) {
+        pipe_next_chunk(P);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) glds_piece(P.lane16, P.cur_src + i * 1024, P.cur_dst + i * 1024);
+    }
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    P.rd_slot_off = 0;
+    P.rd_base = P.ring_lane;
+#pragma unroll
+    for (int j = 0; j < kAhead; ++j) P.a[j] = *(const LDS_AS u32x4 *)(P.rd_base + j * 1024);
+}
+
+// Consume the piece at in-chunk phase PH (0..15): returns its A operand and refills the prefetch slot with the piece kAhead
+// further on.  Phase 8: chunk c + 1 must have landed (every wave waits for its own pieces, then the barrier) and chunk
+// c + kRS - 1's DMA starts into the slot chunk c - 1 occupied.
+template <int PH>
+__device__ __forceinline__ bf16x8 pipe_take(PipeV &P) {
+    if constexpr (PH == 8) {
+        // chunk c + 1 was issued kRS - 2 chunks ago; the 4 (kRS - 3) pieces of the chunks issued since may still be in
+        // flight (VMEM returns in order; any compiler-issued access in between only makes this wait longer, never shorter)
+#if NERF_BV2_DIAG_NO_BARRIER
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (kRS - 3)) : "memory");
+#else
+        asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(4 * (kRS - 3)) : "memory");
+#endif
+        pipe_next_chunk(P);
+    }
+#if NERF_BV2_DIAG_NO_LDS
+    if constexpr (PH != 0) { u32x4 a = P.a[0]; asm volatile("" : "+v"(a)); return __builtin_bit_cast(bf16x8, a); }
+#endif
+    const u32x4 a = P.a[PH % kAhead];
+    if constexpr (PH + kAhead == 16) { // the piece to prefetch is the first of the next chunk
+        uint32_t off = P.rd_slot_off + kCB;
+        off = (off == kRS * kCB) ? 0u : off;
+        P.rd_slot_off = off;
+        P.rd_base = P.ring_lane + off;
+    }
+    P.a[PH % kAhead] = *(const LDS_AS u32x4 *)(P.rd_base + ((PH + kAhead) % 16) * 1024);
+    return __builtin_bit_cast(bf16x8, a);
+}
+
+// LDS-DMA piece whose instruction offset OFF advances the global AND the LDS address (both = base + OFF + lane * 16): the four
+// pieces of a wave's chunk quarter share one scalar base pair and one M0 value.
+template <int OFF>
+__device__ __forceinline__ void glds_piece_off(uint32_t lane16, const char *gsrc, uint32_t dst) {
+    uint32_t keep;
+#if NERF_BV2_DMA_INST_OFFSET
+    asm volatile("s_mov_b32 %0, m0\n\t"
+                 "s_mov_b32 m0, %3\n\t"
+                 "s_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, %2 offset:%4\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(lane16), "s"(gsrc), "s"(dst), "n"(OFF)
+                 : "memory");
+#else
+    (void)keep;
+    glds_piece(lane16, gsrc + OFF, dst + OFF);
+#endif
+}
+
+template <int PH>
+__device__ __forceinline__ void pipe_dma(PipeV &P) {
+#if NERF_BV2_DIAG_NO_DMA
+    return;
+#endif
+    if constexpr (PH >= 9 && (PH & 1) == 1) glds_piece_off<((PH - 9) / 2) * 1024>(P.lane16, P.cur_src, P.cur_dst);
+}
+
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
+
+// two f32 -> one packed bf16 pair (RNE); ReLU as a packed signed-16-bit max (a negative bf16 is a negative int16)
+template <bool RELU>
+__device__ __forceinline__ uint32_t pack2(float x, float y) {
+    const f32x2 p = {x, y};
+    bf16x2 c = __builtin_convertvector(p, bf16x2);
+    if (RELU) {
+        s16x2 i = __builtin_bit_cast(s16x2, c);
+        i = __builtin_elementwise_max(i, (s16x2){0, 0});
+        return __builtin_bit_cast(uint32_t, i);
+    }
+    return __builtin_bit_cast(uint32_t, c);
+}
+
+// a 16-register f32 tile -> its two packed k-steps (registers 0..7 -> k0, 8..15 -> k1); used for the encodings
+__device__ __forceinline__ void pack_tile(const f32x16 &t, u32x4 &k0, u32x4 &k1) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        k0[q] = pack2<false>(t[2 * q], t[2 * q + 1]);
+        k1[q] = pack2<false>(t[8 + 2 * q], t[8 + 2 * q + 1]);
+    }
+}
+
+struct Heads {
+    float alpha[2];  // per sub-tile partial sums over this lane's features
+    float rgb[2][3];
+};
+
+// Epilogue of one register pair PR (0..7) of a finished output tile for ONE sub-tile (4 VALU when only converting: two
+// accumulator reads, v_cvt_pk_bf16_f32, v_pk_max_i16 -- sized to hide in one MFMA gap).
+// HEAD 0: convert only; 1: convert + alpha partial sums; 2: alpha only (sigma kernels); 3: rgb partial sums only.
+template <int PR, int SUB, bool RELU, int HEAD, int NTI>
+__device__ __forceinline__ void convert_half(const f32x16 &acc, u32x4 &na, u32x4 &nb, Heads &H, const LDS_AS float *small, int h) {
+#if NERF_BV2_DIAG_NO_EPILOGUE
+    if constexpr (PR != 0) return;
+#endif
+    constexpr int r0 = 2 * PR, r1 = 2 * PR + 1;
+    const float x0 = acc[r0], x1 = acc[r1];
+    if constexpr (HEAD == 1 || HEAD == 2) { // alpha = sum_F w[F] relu(h8[F]) in f32 (src/network.rs:216)
+        const f32x2 w = *(const LDS_AS f32x2 *)(small + kAlphaWOff + h * 128 + NTI * 16 + r0);
+        H.alpha[SUB] = fmaf(w[1], relu(x1), fmaf(w[0], relu(x0), H.alpha[SUB]));
+    }
+    if constexpr (HEAD == 3) { // rgb pre-activations from relu(viewdirs) in f32 (src/network.rs:222-223)
+        const float a0 = relu(x0), a1 = relu(x1);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const f32x2 w = *(const LDS_AS f32x2 *)(small + kRgbWOff + (h * 3 + c) * 64 + NTI * 16 + r0);
+            H.rgb[SUB][c] = fmaf(w[1], a1, fmaf(w[0], a0, H.rgb[SUB][c]));
+        }
+    }
+    if constexpr (HEAD == 0 || HEAD == 1) {
+        const uint32_t c = pack2<RELU>(x0, x1);
+        if constexpr (PR < 4) na[PR] = c;
+        else                  nb[PR - 4] = c;
+    }
+}
+
+// this lane-half's 16 bias values of output tile nt ([nt][h][16] in LDS)
+__device__ __forceinline__ void load_bias(f32x16 &b, const LDS_AS float *bias, int nt, int h) {
+    const LDS_AS f32x4 *src = (const LDS_AS f32x4 *)(bias + (nt * 2 + h) * 16);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const f32x4 v = src[q];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) b[4 * q + e] = v[e];
+    }
+}
+
+// k-step of the NEXT tile behind whose MFMAs pair pr of a finished tile is converted: spread over steps 1 .. KS - 1 (not step
+// 0: reading an accumulator right behind the MFMA that finished it costs the MFMA-write -> VALU-read wait states)
+template <int KS>
+constexpr int pair_step(int pr) { return 1 + pr * (KS - 1) / 8; }
+
+#if NERF_BV2_SCHED_BARRIER
+#define BV2_PIN() __builtin_amdgcn_sched_barrier(0)
+#else
+#define BV2_PIN() ((void)0)
+#endif
+
+// One output tile NTI of a layer: KS pieces from stream phase PH (piece index mod 16), 2 MFMAs per piece.  `bv` holds this
+// tile's bias (loaded one tile ahead) and is the C operand of the first MFMA pair; the next tile's bias is loaded into it
+// right after.  The previous tile's epilogue (p0, p1 -> out*[2 (NTI - 1)], [2 (NTI - 1) + 1]) is spread over the MFMA gaps:
+// pair pr at step pair_step(pr), sub-tile 0's half behind the first MFMA of the step, sub-tile 1's behind the second.
+template <int KS, int NT, int NTI, int PH, bool RELU_OUT, int HEAD>
+__device__ __forceinline__ void out_tile(const u32x4 (&in0)[KS], const u32x4 (&in1)[KS], u32x4 (&out0)[16], u32x4 (&out1)[16], f32x16 &c0,
+                                         f32x16 &c1, const f32x16 &p0, const f32x16 &p1, f32x16 &bv, const LDS_AS float *bias,
+                                         const LDS_AS float *small, Heads &H, PipeV &P, int h) {
+    constexpr int o = (2 * (NTI > 0 ? NTI - 1 : 0)) & 15;
+    static_for<0, KS>([&](auto ks_c) {
+        constexpr int ks = decltype(ks_c)::value;
+        constexpr int ph = (PH + ks) % 16;
+        const bf16x8 a = pipe_take<ph>(P);
+        if constexpr (ks == 0) c0 = MFMA16(a, __builtin_bit_cast(bf16x8, in0[ks]), bv);
+        else                   c0 = MFMA16(a, __builtin_bit_cast(bf16x8, in0[ks]), c0);
+        BV2_PIN();
+        if constexpr (NTI > 0)
+            static_for<0, 8>([&](auto pr_c) {
+                constexpr int pr = decltype(pr_c)::value;
+                if constexpr (pair_step<KS>(pr) == ks) convert_half<pr, 0, RELU_OUT, HEAD, NTI - 1>(p0, out0[o], out0[o + 1], H, small, h);
+            });
+        pipe_dma<ph>(P);
+        BV2_PIN();
+        if constexpr (ks == 0) c1 = MFMA16(a, __builtin_bit_cast(bf16x8, in1[ks]), bv);
+        else                   c1 = MFMA16(a, __builtin_bit_cast(bf16x8, in1[ks]), c1);
+        BV2_PIN();
+        if constexpr (NTI > 0)
+            static_for<0, 8>([&](auto pr_c) {
+                constexpr int pr = decltype(pr_c)::value;
+                if constexpr (pair_step<KS>(pr) == ks) convert_half<pr, 1, RELU_OUT, HEAD, NTI - 1>(p1, out1[o], out1[o + 1], H, small, h);
+            });
+        if constexpr (ks == 1 && NTI + 1 < NT) load_bias(bv, bias, NTI + 1, h); // the first MFMA pair has consumed bv
+        BV2_PIN();
+    });
+}
+
+// One layer: NT output tiles, accumulators double-buffered (even tiles set A, odd tiles set B); the last tile's epilogue is
+// a tail burst.  Every layer starts at stream phase 0 (layers are whole chunks; viewdirs is padded).
+template <int KS, int NT, bool RELU_OUT, int HEAD>
+__device__ __forceinline__ void layer(const u32x4 (&in0)[KS], const u32x4 (&in1)[KS], u32x4 (&out0)[16], u32x4 (&out1)[16],
+                                      const LDS_AS float *bias, const LDS_AS float *small, Heads &H, PipeV &P, int h) {
+    f32x16 a0, a1, b0, b1, bv;
+    load_bias(bv, bias, 0, h);
+    static_for<0, NT>([&](auto nt_c) {
+        constexpr int nt = decltype(nt_c)::value;
+        constexpr int ph = (nt * KS) % 16;
+        if constexpr ((nt & 1) == 0) out_tile<KS, NT, nt, ph, RELU_OUT, HEAD>(in0, in1, out0, out1, a0, a1, b0, b1, bv, bias, small, H, P, h);
+        else                         out_tile<KS, NT, nt, ph, RELU_OUT, HEAD>(in0, in1, out0, out1, b0, b1, a0, a1, bv, bias, small, H, P, h);
+    });
+    constexpr int o = (2 * (NT - 1)) & 15;
+    const f32x16 &l0 = ((NT - 1) & 1) ? b0 : a0, &l1 = ((NT - 1) & 1) ? b1 : a1;
+    static_for<0, 8>([&](auto pr_c) {
+        constexpr int pr = decltype(pr_c)::value;
+        convert_half<pr, 0, RELU_OUT, HEAD, NT - 1>(l0, out0[o], out0[o + 1], H, small, h);
+        convert_half<pr, 1, RELU_OUT, HEAD, NT - 1>(l1, out1[o], out1[o + 1], H, small, h);
+    });
+}
+
+} // namespace
+
+template <bool FULL, int MODE>
+__global__ __launch_bounds__(256, 1) void nerf_mlp_kernel_bf16v2(const MlpArgs A) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const LDS_AS char *lds = (const LDS_AS char *)smem;
+    const LDS_AS float *small = (const LDS_AS float *)(lds + kRS * kCB);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int p = lane & 31;
+    const int h = lane >> 5;
+
+    {
+        float *dst = (float *)(smem + kRS * kCB);
+        for (int i = tid; i < kSmallFloats; i += 256) dst[i] = A.small_params[i];
+    }
+    PipeV P;
+    P.lane16 = lane * 16;
+    P.ring_lane = lds + P.lane16;
+    P.ring_addr = (uint32_t)(uintptr_t)lds + wave * 4096;
+    P.stream_bytes = (FULL ? kChunksFullBf16V2 : kChunksSigmaBf16V2) * kCB;
+    P.gbase = (const char *)A.wstream + wave * 4096;
+    __syncthreads();
+    pipe_start(P);
+    uint64_t clk0 = 0, rt0 = 0;
+    if (A.clock_out) { clk0 = __builtin_amdgcn_s_memtime(); rt0 = __builtin_amdgcn_s_memrealtime(); }
+
+    const int n_tiles = (A.n_points + kPointsPerBlockBf16V2 - 1) / kPointsPerBlockBf16V2;
+    auto raw = [&](int tile_idx, int sub) -> RawIn { // clamped: padding lanes and the look-ahead tile read the last point
+        RawIn r;
+        int i = tile_idx * kPointsPerBlockBf16V2 + wave * 64 + sub * 32 + p;
+        i = i < A.n_points ? i : A.n_points - 1;
+        if (MODE == MLP_MODE_POINTS) {
+            r.a = A.pts_soa[i]; r.b = A.pts_soa[(size_t)A.n_points + i]; r.c = A.pts_soa[2 * (size_t)A.n_points + i];
+            r.dx = A.dirs_aos[3 * (size_t)i]; r.dy = A.dirs_aos[3 * (size_t)i + 1]; r.dz = A.dirs_aos[3 * (size_t)i + 2];
+        } else {
+            const int ray = i / A.samples_per_ray;
+            r.a = A.t[i]; r.b = 0.f; r.c = 0.f;
+            r.dx = A.ray_dirs[3 * (size_t)ray]; r.dy = A.ray_dirs[3 * (size_t)ray + 1]; r.dz = A.ray_dirs[3 * (size_t)ray + 2];
+        }
+        return r;
+    };
+#if NERF_BV2_PREFETCH_INPUTS
+    RawIn nx0 = raw(blockIdx.x, 0), nx1 = raw(blockIdx.x, 1);
+#endif
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int i0 = tile * kPointsPerBlockBf16V2 + wave * 64 + p, i1 = i0 + 32;
+        const bool v0 = i0 < A.n_points, v1 = i1 < A.n_points;
+#if NERF_BV2_PREFETCH_INPUTS
+        const RawIn in0 = nx0, in1 = nx1;
+        const int nt_idx = tile + gridDim.x < n_tiles ? tile + gridDim.x : tile;
+        nx0 = raw(nt_idx, 0); nx1 = raw(nt_idx, 1);
+#else
+        const RawIn in0 = raw(tile, 0), in1 = raw(tile, 1);
+#endif
+
+        // position encodings -> 4 packed k-steps per sub-tile
+        u32x4 E0[4], E1[4];
+        {
+            float px, py, pz;
+            f32x16 E[2];
+            point_of<MODE>(A, in0, px, py, pz);
+            encode_point<true>(px, py, pz, h, E);
+            pack_tile(E[0], E0[0], E0[1]); pack_tile(E[1], E0[2], E0[3]);
+            point_of<MODE>(A, in1, px, py, pz);
+            encode_point<true>(px, py, pz, h, E);
+            pack_tile(E[0], E1[0], E1[1]); pack_tile(E[1], E1[2], E1[3]);
+        }
+        u32x4 X0[16], X1[16], Y0[16], Y1[16];
+        Heads H;
+        H.alpha[0] = H.alpha[1] = 0.f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) H.rgb[0][c] = H.rgb[1][c] = 0.f;
+
+        layer<4, 8, true, 0>(E0, E1, X0, X1, small + kBiasOff + 0 * 256, small, H, P, h);   // dense0 (src/network.rs:204)
+        layer<16, 8, true, 0>(X0, X1, Y0, Y1, small + kBiasOff + 1 * 256, small, H, P, h);
+        layer<16, 8, true, 0>(Y0, Y1, X0, X1, small + kBiasOff + 2 * 256, small, H, P, h);
+        layer<16, 8, true, 0>(X0, X1, Y0, Y1, small + kBiasOff + 3 * 256, small, H, P, h);
+        layer<16, 8, true, 0>(Y0, Y1, X0, X1, small + kBiasOff + 4 * 256, small, H, P, h);
+        {   // dense5 on [encoding (4 k-steps) ; h4 (16 k-steps)] (src/network.rs:209-210)
+            u32x4 C0[20], C1[20];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { C0[k] = E0[k]; C1[k] = E1[k]; }
+#pragma unroll
+            for (int k = 0; k < 16; ++k) { C0[4 + k] = X0[k]; C1[4 + k] = X1[k]; }
+            layer<20, 8, true, 0>(C0, C1, Y0, Y1, small + kBiasOff + 5 * 256, small, H, P, h);
+        }
+        layer<16, 8, true, 0>(Y0, Y1, X0, X1, small + kBiasOff + 6 * 256, small, H, P, h);
+        // dense7: alpha head from the f32 accumulators; the packed h8 is only needed when the colour branch follows
+        layer<16, 8, true, FULL ? 1 : 2>(X0, X1, Y0, Y1, small + kBiasOff + 7 * 256, small, H, P, h);
+        const float s0 = fmaxf(xhalf_sum(H.alpha[0]) + small[kMiscOff + 0], 0.f); // ReLU(alpha) (src/network.rs:216)
+        const float s1 = fmaxf(xhalf_sum(H.alpha[1]) + small[kMiscOff + 0], 0.f);
+        if (h == 0) {
+            if (v0) A.sigma_out[i0] = s0;
+            if (v1) A.sigma_out[i1] = s1;
+        }
+        if constexpr (FULL) {
+            if (A.skip_empty) { // exact empty-tile skip, see mlp_kernel.hip: all 256 sigmas are 0 -> colours are never used
+                LDS_AS int *vote = (LDS_AS int *)(lds + kRS * kCB) + kMiscOff + 8;
+                const bool any_wg = tile_has_density(vote, (v0 && s0 > 0.0f) || (v1 && s1 > 0.0f), wave, lane);
+                if (!any_wg) {
+                    if (h == 0) {
+                        if (v0) { A.rgb_out[3 * (size_t)i0] = 0.f; A.rgb_out[3 * (size_t)i0 + 1] = 0.f; A.rgb_out[3 * (size_t)i0 + 2] = 0.f; }
+                        if (v1) { A.rgb_out[3 * (size_t)i1] = 0.f; A.rgb_out[3 * (size_t)i1 + 1] = 0.f; A.rgb_out[3 * (size_t)i1 + 2] = 0.f; }
+                    }
+                    if (A.skip_counter && tid == 0) atomicAdd(A.skip_counter, 2ull); // counter unit = 128 points
+                    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");     // in-flight chunks landed; ring idle
+                    pipe_start(P);
+                    continue;
+                }
+            }
+            layer<16, 8, false, 0>(Y0, Y1, X0, X1, small + kBiasOff + 8 * 256, small, H, P, h); // bottleneck: no activation (:218)
+            u32x4 V0[18], V1[18];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) { V0[k] = X0[k]; V1[k] = X1[k]; }
+            {
+                f32x16 D;
+                encode_dir<true>(in0.dx, in0.dy, in0.dz, h, D); pack_tile(D, V0[16], V0[17]);
+                encode_dir<true>(in1.dx, in1.dy, in1.dz, h, D); pack_tile(D, V1[16], V1[17]);
+            }
+            layer<18, 4, true, 3>(V0, V1, Y0, Y1, small + kBiasViewOff, small, H, P, h); // viewdirs + rgb partial sums (:220-223)
+            {   // viewdirs' 72 pieces end at phase 8; the stream carries 8 zero pieces up to the chunk end: step over them
+                bf16x8 d;
+                d = pipe_take<8>(P);                   asm volatile("" ::"v"(d));
+                d = pipe_take<9>(P);  pipe_dma<9>(P);  asm volatile("" ::"v"(d));
+                d = pipe_take<10>(P);                  asm volatile("" ::"v"(d));
+                d = pipe_take<11>(P); pipe_dma<11>(P); asm volatile("" ::"v"(d));
+                d = pipe_take<12>(P);                  asm volatile("" ::"v"(d));
+                d = pipe_take<13>(P); pipe_dma<13>(P); asm volatile("" ::"v"(d));
+                d = pipe_take<14>(P);                  asm volatile("" ::"v"(d));
+                d = pipe_take<15>(P); pipe_dma<15>(P); asm volatile("" ::"v"(d));
+            }
+            float c0[3], c1[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { // sigmoid (src/network.rs:165)
+                c0[c] = 1.0f / (1.0f + expf(-(xhalf_sum(H.rgb[0][c]) + small[kMiscOff + 1 + c])));
+                c1[c] = 1.0f / (1.0f + expf(-(xhalf_sum(H.rgb[1][c]) + small[kMiscOff + 1 + c])));
+            }
+            if (h == 0) {
+                if (v0) { A.rgb_out[3 * (size_t)i0] = c0[0]; A.rgb_out[3 * (size_t)i0 + 1] = c0[1]; A.rgb_out[3 * (size_t)i0 + 2] = c0[2]; }
+                if (v1) { A.rgb_out[3 * (size_t)i1] = c1[0]; A.rgb_out[3 * (size_t)i1 + 1] = c1[1]; A.rgb_out[3 * (size_t)i1 + 2] = c1[2]; }
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // no LDS-DMA may be in flight when the workgroup's LDS is released
+    if (A.clock_out && tid == 0) { // diagnostic: shader clock = d(memtime) / d(memrealtime) x 100 MHz
+        A.clock_out[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - clk0;
+        A.clock_out[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - rt0;
+    }
+}
+
+template <bool FULL, int MODE>
+static hipError_t launch_t(const MlpArgs &a, int n_blocks, hipStream_t stream) {
+    hipLaunchKernelGGL((nerf_mlp_kernel_bf16v2<FULL, MODE>), dim3(n_blocks), dim3(256), kLdsBytesBf16V2, stream, a);
+    return hipGetLastError();
+}
+
+hipError_t nerf_mlp_bf16v2_init() {
+    const void *ks[4] = {(const void *)nerf_mlp_kernel_bf16v2<true, MLP_MODE_POINTS>, (const void *)nerf_mlp_kernel_bf16v2<false, MLP_MODE_POINTS>,
+                         (const void *)nerf_mlp_kernel_bf16v2<true, MLP_MODE_RAYS>, (const void *)nerf_mlp_kernel_bf16v2<false, MLP_MODE_RAYS>};
+    for (int i = 0; i < 4; ++i) {
+        hipError_t e = hipFuncSetAttribute(ks[i], hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytesBf16V2);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
+hipError_t nerf_mlp_bf16v2_launch(const MlpArgs &a, bool full, int n_blocks, hipStream_t stream) {
+    if (a.n_points <= 0) return hipSuccess;
+    const int n_tiles = (a.n_points + kPointsPerBlockBf16V2 - 1) / kPointsPerBlockBf16V2;
+    if (n_blocks > n_tiles) n_blocks = n_tiles;
+    if (n_blocks < 1) n_blocks = 1;
+    if (a.mode == MLP_MODE_POINTS)
+        return full ? launch_t<true, MLP_MODE_POINTS>(a, n_blocks, stream) : launch_t<false, MLP_MODE_POINTS>(a, n_blocks, stream);
+    return full ? launch_t<true, MLP_MODE_RAYS>(a, n_blocks, stream) : launch_t<false, MLP_MODE_RAYS>(a, n_blocks, stream);
+}

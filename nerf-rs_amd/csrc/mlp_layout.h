@@ -60,6 +60,19 @@ constexpr int kChunksSigmaBf16 = 1 + 4 * 4 + 5 + 2 * 4;        // dense0 (2 tile
 constexpr int kChunksFullBf16 = kChunksSigmaBf16 + 4 + 3;       // + bottleneck + viewdirs (padded) = 37
 constexpr int kLdsBytesBf16 = kRingSlotsBf16 * kChunkBytesBf16 + kSmallBytes;
 
+// ---- bf16 stream v2 (mlp_kernel_bf16v2.hip): output-tile-major.  Per layer, per output tile nt, per k-step (K = 16) one
+// 1-KiB piece; 16-KiB chunks of 16 pieces.  Pieces per layer: dense0 8 x 4, hidden 8 x 16, dense5 8 x 20, viewdirs 4 x 18
+// (+ 8 zero pieces so that the stream ends on a chunk boundary).  64 points per wave, 256 per workgroup.
+constexpr int kChunkBytesBf16V2 = 16384;
+#ifndef NERF_BV2_RING_SLOTS
+#define NERF_BV2_RING_SLOTS 6
+#endif
+constexpr int kRingSlotsBf16V2 = NERF_BV2_RING_SLOTS; // 3..8: chunk c + kRingSlots - 1 is DMA'd while chunk c is consumed (a chunk lasts ~0.45 us)
+constexpr int kChunksSigmaBf16V2 = (32 + 4 * 128 + 160 + 2 * 128) / 16; // 60
+constexpr int kChunksFullBf16V2 = kChunksSigmaBf16V2 + (128 + 72 + 8) / 16; // 73
+constexpr int kLdsBytesBf16V2 = kRingSlotsBf16V2 * kChunkBytesBf16V2 + kSmallBytes;
+constexpr int kPointsPerBlockBf16V2 = 256;
+
 // feature held by register r (0..15) of a tile on lane-half h, relative to the tile's first feature
 constexpr int regFeature(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 

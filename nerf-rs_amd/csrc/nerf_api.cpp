@@ -30,6 +30,7 @@ thread_local std::string g_err; // context-free calls
 struct DevNet {
     float *wstream = nullptr, *small = nullptr;
     uint16_t *wstream_bf16 = nullptr; // built from the same tensors at load time (mlp_kernel_bf16.hip)
+    uint16_t *wstream_bf16v2 = nullptr; // the same pieces in output-tile-major order (mlp_kernel_bf16v2.hip)
     bool loaded = false;
 };
 
@@ -44,6 +45,7 @@ struct EvPair {
 struct nerf_ctx {
     int device = 0;
     int n_cus = 0;
+    bool bf16_v1 = false; // NERF_BF16_KERNEL=v1 selects the first bf16 design (mlp_kernel_bf16.hip) for A/B runs
     std::string arch;
     std::string err;
     hipStream_t stream = nullptr; // used by the host-pointer entry points
@@ -139,10 +141,46 @@ int ensure_workspace(nerf_ctx *c, size_t rays, size_t nc, size_t m) {
 
 int upload_packed(nerf_ctx *c, int which, const std::vector<float> &ws, const std::vector<float> &sm);
 
+// weight stream + launcher of the selected arithmetic
+static const float *stream_of(const nerf_ctx *c, const DevNet &n, bool bf16) {
+    return !bf16 ? n.wstream : (const float *)(c->bf16_v1 ? n.wstream_bf16 : n.wstream_bf16v2);
+}
+static hipError_t launch_mlp(const nerf_ctx *c, bool bf16, const MlpArgs &a, bool full, hipStream_t st) {
+    if (!bf16) return nerf_mlp_launch(a, full, c->n_cus, st);
+    return c->bf16_v1 ? nerf_mlp_bf16_launch(a, full, c->n_cus, st) : nerf_mlp_bf16v2_launch(a, full, c->n_cus, st);
+}
+
+// v1 stream -> v2 stream: the 1-KiB pieces are identical (lane l, element j = W[row(tile, 8 ks + j, l >> 5)][32 nt + (l & 31)]);
+// v1 orders a layer's pieces (k-step, nt), v2 orders them (nt, k-step) and pads viewdirs' 72 pieces to 80.
+static void bf16_v2_from_v1(const std::vector<uint16_t> &v1, std::vector<uint16_t> &v2) {
+    using namespace nerfmlp;
+    v2.clear();
+    v2.reserve((size_t)kChunksFullBf16V2 * kChunkBytesBf16V2 / 2);
+    size_t base = 0; // uint16 elements
+    auto layer = [&](int KS, int NT) {
+        for (int nt = 0; nt < NT; ++nt)
+            for (int ks = 0; ks < KS; ++ks) {
+                const uint16_t *src = &v1[base + ((size_t)ks * NT + nt) * 512];
+                v2.insert(v2.end(), src, src + 512);
+            }
+        base += (size_t)KS * NT * 512;
+    };
+    layer(4, 8);
+    for (int i = 0; i < 4; ++i) layer(16, 8);
+    layer(20, 8);
+    for (int i = 0; i < 3; ++i) layer(16, 8);
+    layer(18, 4);
+    v2.resize((size_t)kChunksFullBf16V2 * kChunkBytesBf16V2 / 2, (uint16_t)0);
+}
+
 int upload_bf16(nerf_ctx *c, int which, const std::vector<uint16_t> &wb) {
     DevNet &d = c->net[which];
     if (!d.wstream_bf16) HIP_TRY(c, hipMalloc((void **)&d.wstream_bf16, wb.size() * sizeof(uint16_t)));
     HIP_TRY(c, hipMemcpy(d.wstream_bf16, wb.data(), wb.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    std::vector<uint16_t> v2;
+    bf16_v2_from_v1(wb, v2);
+    if (!d.wstream_bf16v2) HIP_TRY(c, hipMalloc((void **)&d.wstream_bf16v2, v2.size() * sizeof(uint16_t)));
+    HIP_TRY(c, hipMemcpy(d.wstream_bf16v2, v2.data(), v2.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
     return NERF_OK;
 }
 
@@ -289,13 +327,13 @@ int render_device(nerf_ctx *c, const nerf_camera *cam, const nerf_render_opts *o
         a.ray_dirs = c->d_dirs;
         a.origin[0] = cam->pos[0]; a.origin[1] = cam->pos[1]; a.origin[2] = cam->pos[2];
         // coarse network: sigma only unless its colours are composited (reference discards them, src/lib.rs:404)
-        a.wstream = bf16 ? (const float *)NC.wstream_bf16 : NC.wstream; a.small_params = NC.small;
+        a.wstream = stream_of(c, NC, bf16); a.small_params = NC.small;
         a.n_points = n_rays * nc; a.samples_per_ray = nc; a.t = c->d_tc;
         a.sigma_out = c->d_sc; a.rgb_out = c->d_rgbc;
         a.skip_empty = o->skip_empty; a.skip_counter = o->skip_empty ? c->d_skip : nullptr; // only full kernels look at it
         {
             Timed t(c, st, o->coarse_only ? 1 : 0, (uint64_t)a.n_points, timing);
-            HIP_TRY(c, (bf16 ? nerf_mlp_bf16_launch : nerf_mlp_launch)(a, o->coarse_only != 0, c->n_cus, st));
+            HIP_TRY(c, launch_mlp(c, bf16, a, o->coarse_only != 0, st));
             t.done(c->last_render);
         }
         float *pass_out = ray_out + (size_t)row * RW * 3;
@@ -319,14 +357,14 @@ int render_device(nerf_ctx *c, const nerf_camera *cam, const nerf_render_opts *o
             t.done(c->last_render);
             t_fine = c->d_tf;
         }
-        a.wstream = bf16 ? (const float *)NF.wstream_bf16 : NF.wstream; a.small_params = NF.small;
+        a.wstream = stream_of(c, NF, bf16); a.small_params = NF.small;
         a.n_points = n_rays * M; a.samples_per_ray = M; a.t = t_fine;
         a.sigma_out = c->d_sf; a.rgb_out = c->d_rgbf;
         a.clock_out = c->d_clock; // NULL unless NERF_DEBUG_CLOCK=1
-        c->clock_valid = c->d_clock != nullptr && !bf16; // only the f32 kernel writes the stamps
+        c->clock_valid = c->d_clock != nullptr && !(bf16 && c->bf16_v1); // the first bf16 design does not write the stamps
         {
             Timed t(c, st, 1, (uint64_t)a.n_points, timing);
-            HIP_TRY(c, (bf16 ? nerf_mlp_bf16_launch : nerf_mlp_launch)(a, true, c->n_cus, st));
+            HIP_TRY(c, launch_mlp(c, bf16, a, true, st));
             t.done(c->last_render);
         }
         ca.n = M; ca.t = t_fine; ca.sigma = c->d_sf; ca.rgb = c->d_rgbf;
@@ -409,9 +447,11 @@ int nerf_create(int device_id, nerf_ctx **out) {
     if (const char *env = getenv("NERF_DEBUG_CLOCK")) {
         if (atoi(env) > 0 && hipMalloc((void **)&c->d_clock, (size_t)c->n_cus * 2 * sizeof(unsigned long long)) != hipSuccess) c->d_clock = nullptr;
     }
+    if (const char *env = getenv("NERF_BF16_KERNEL")) c->bf16_v1 = std::string(env) == "v1";
     if (hipMalloc((void **)&c->d_skip, sizeof(unsigned long long)) != hipSuccess) c->d_skip = nullptr;
     hipError_t e1 = nerf_mlp_init();
     if (e1 == hipSuccess) e1 = nerf_mlp_bf16_init();
+    if (e1 == hipSuccess) e1 = nerf_mlp_bf16v2_init();
     hipError_t e2 = e1 == hipSuccess ? sampling_init() : e1;
     hipError_t e3 = e2 == hipSuccess ? hipStreamCreate(&c->stream) : e2;
     if (e3 != hipSuccess) {
@@ -427,7 +467,7 @@ void nerf_destroy(nerf_ctx *c) {
     if (!c) return;
     DeviceGuard dg(c->device);
     (void)hipDeviceSynchronize();
-    for (auto &n : c->net) { if (n.wstream) (void)hipFree(n.wstream); if (n.small) (void)hipFree(n.small); if (n.wstream_bf16) (void)hipFree(n.wstream_bf16); }
+    for (auto &n : c->net) { if (n.wstream) (void)hipFree(n.wstream); if (n.small) (void)hipFree(n.small); if (n.wstream_bf16) (void)hipFree(n.wstream_bf16); if (n.wstream_bf16v2) (void)hipFree(n.wstream_bf16v2); }
     float *ptrs[] = {c->d_dirs, c->d_tc, c->d_sc, c->d_rgbc, c->d_tf, c->d_sf, c->d_rgbf, c->d_rayfb, c->d_out};
     for (float *p : ptrs) if (p) (void)hipFree(p);
     if (c->d_scratch) (void)hipFree(c->d_scratch);
@@ -588,9 +628,9 @@ static int forward_device(nerf_ctx *c, int which, int dtype, const float *d_pts,
     a.mode = MLP_MODE_POINTS;
     if (dtype != NERF_MLP_F32 && dtype != NERF_MLP_BF16) return fail(c, NERF_ERR_INVALID, "mlp_dtype must be NERF_MLP_F32 or NERF_MLP_BF16");
     const bool bf16 = dtype == NERF_MLP_BF16;
-    a.wstream = bf16 ? (const float *)c->net[which].wstream_bf16 : c->net[which].wstream; a.small_params = c->net[which].small;
+    a.wstream = stream_of(c, c->net[which], bf16); a.small_params = c->net[which].small;
     a.n_points = (int)n; a.pts_soa = d_pts; a.dirs_aos = d_dirs; a.sigma_out = d_sigma; a.rgb_out = d_rgb;
-    HIP_TRY(c, (bf16 ? nerf_mlp_bf16_launch : nerf_mlp_launch)(a, true, c->n_cus, (hipStream_t)stream));
+    HIP_TRY(c, launch_mlp(c, bf16, a, true, (hipStream_t)stream));
     return NERF_OK;
 }
 
