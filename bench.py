@@ -181,7 +181,7 @@ def main():
         ms = 1e3 * (time.perf_counter() - t1) / 2
         extra_skip = {"rays_per_s": args.width * args.height * args.ssaa * args.ssaa / (ms * 1e-3), "ms_per_step": ms,
                       "image_bit_identical_to_headline_run": identical,
-                      "note": "opt-in skip_empty: colour head skipped for 128-sample tiles whose densities are all 0 (exact)"}
+                      "note": "opt-in skip_empty: colour head skipped for workgroup tiles (128 samples f32, 256 bf16) whose densities are all 0 (exact)"}
         r.kernel_time_query(reset=True)
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     if use_dist:
@@ -212,7 +212,8 @@ def main():
                        "whole_job_fraction_of_mfma_roofline": value * flop_ray / (world * peak * 1e12)},
             "roofline": {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
                          "frac": ach / peak, "traffic": None if bf16 else pmc_traffic_bytes(),
-                         "kernel": ("nerf_mlp_kernel_bf16" if bf16 else "nerf_mlp_kernel") + "<FULL=true, MODE_RAYS> (fine network)",
+                         "kernel": (("nerf_mlp_kernel_bf16" if os.environ.get("NERF_BF16_KERNEL") == "v1" else "nerf_mlp_kernel_bf16v2") if bf16
+                                    else "nerf_mlp_kernel") + "<FULL=true, MODE_RAYS> (fine network)",
                          "launches": n_dom, "avg_launch_ms": ms_dom / max(n_dom, 1),
                          "points_per_launch": pts_dom // max(n_dom, 1), "flop_per_point": N.FLOP_PER_POINT_FULL},
         }

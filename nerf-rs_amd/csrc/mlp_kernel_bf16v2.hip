@@ -42,6 +42,22 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 #ifndef NERF_BV2_DMA_INST_OFFSET
 #define NERF_BV2_DMA_INST_OFFSET 1 // one scalar base + M0 per chunk quarter, pieces addressed by the instruction offset
 #endif
+#ifndef NERF_BV2_DOUBLING
+#define NERF_BV2_DOUBLING 1 // encodings by angle doubling from each lane-half's base octave (mlp_common.hip.h)
+#endif
+#if NERF_BV2_DOUBLING
+#define ENCODE_POINT encode_point_doubling
+#define ENCODE_DIR encode_dir_doubling
+#else
+#define ENCODE_POINT encode_point<true>
+#define ENCODE_DIR encode_dir<true>
+#endif
+#ifndef NERF_BV2_M0_NOSAVE
+#define NERF_BV2_M0_NOSAVE 0 // 1: drop the M0 save/restore around each LDS-DMA piece (+0.3 %; relies on hipcc not using M0)
+#endif
+#ifndef NERF_BV2_PAIR_READS
+#define NERF_BV2_PAIR_READS 1 // A operands fetched two pieces at a time, one s_waitcnt per pair
+#endif
 #ifndef NERF_BV2_AHEAD
 #define NERF_BV2_AHEAD 4
 #endif
@@ -76,7 +92,7 @@ struct PipeV {
     const LDS_AS char *rd_base;   // LDS address (incl. lane * 16) of the chunk the next prefetched piece lives in
     const LDS_AS char *ring_lane;
     uint32_t rd_slot_off;
-    u32x4 a[kAhead];              // prefetched A operands of the next kAhead pieces
+    u32x4 a[8];                   // ring of prefetched A operands (piece phase mod 8); kAhead (+1) of them are live
     uint32_t ring_addr, wr_slot_off, next_off, stream_bytes;
     const char *gbase, *cur_src;
     uint32_t cur_dst, lane16;
@@ -129,23 +145,52 @@ __device__ __forceinline__ bf16x8 pipe_take(PipeV &P) {
 #if NERF_BV2_DIAG_NO_LDS
     if constexpr (PH != 0) { u32x4 a = P.a[0]; asm volatile("" : "+v"(a)); return __builtin_bit_cast(bf16x8, a); }
 #endif
-    const u32x4 a = P.a[PH % kAhead];
+#if NERF_BV2_PAIR_READS
+    static_assert(kAhead % 2 == 0, "paired reads need an even prefetch distance");
+    if constexpr ((PH & 1) == 0) {
+        // both operands of this piece pair are "used" here, so hipcc waits for them with ONE s_waitcnt
+        asm volatile("" : "+v"(P.a[PH % 8]), "+v"(P.a[(PH + 1) % 8]));
+        const u32x4 a = P.a[PH % 8];
+        if constexpr (PH + kAhead == 16) { // the pair to prefetch opens the next chunk
+            uint32_t off = P.rd_slot_off + kCB;
+            off = (off == kRS * kCB) ? 0u : off;
+            P.rd_slot_off = off;
+            P.rd_base = P.ring_lane + off;
+        }
+        P.a[(PH + kAhead) % 8] = *(const LDS_AS u32x4 *)(P.rd_base + ((PH + kAhead) % 16) * 1024);
+        P.a[(PH + kAhead + 1) % 8] = *(const LDS_AS u32x4 *)(P.rd_base + ((PH + kAhead + 1) % 16) * 1024);
+        return __builtin_bit_cast(bf16x8, a);
+    } else {
+        return __builtin_bit_cast(bf16x8, P.a[PH % 8]);
+    }
+#else
+    const u32x4 a = P.a[PH % 8];
     if constexpr (PH + kAhead == 16) { // the piece to prefetch is the first of the next chunk
         uint32_t off = P.rd_slot_off + kCB;
         off = (off == kRS * kCB) ? 0u : off;
         P.rd_slot_off = off;
         P.rd_base = P.ring_lane + off;
     }
-    P.a[PH % kAhead] = *(const LDS_AS u32x4 *)(P.rd_base + ((PH + kAhead) % 16) * 1024);
+    P.a[(PH + kAhead) % 8] = *(const LDS_AS u32x4 *)(P.rd_base + ((PH + kAhead) % 16) * 1024);
     return __builtin_bit_cast(bf16x8, a);
+#endif
 }
 
 // LDS-DMA piece whose instruction offset OFF advances the global AND the LDS address (both = base + OFF + lane * 16): the four
 // pieces of a wave's chunk quarter share one scalar base pair and one M0 value.
 template <int OFF>
 __device__ __forceinline__ void glds_piece_off(uint32_t lane16, const char *gsrc, uint32_t dst) {
+#if NERF_BV2_DMA_INST_OFFSET && NERF_BV2_M0_NOSAVE
+    // M0 is written and read inside this one statement and not restored: hipcc emits no M0 use of its own in this kernel
+    // (no LDS-direct, no s_movrel, no sendmsg; checked on the generated ISA: every m0 reference is one of these statements)
+    asm volatile("s_mov_b32 m0, %2\n\t"
+                 "s_nop 0\n\t"
+                 "global_load_lds_dwordx4 %0, %1 offset:%3"
+                 :
+                 : "v"(lane16), "s"(gsrc), "s"(dst), "n"(OFF)
+                 : "memory");
+#elif NERF_BV2_DMA_INST_OFFSET
     uint32_t keep;
-#if NERF_BV2_DMA_INST_OFFSET
     asm volatile("s_mov_b32 %0, m0\n\t"
                  "s_mov_b32 m0, %3\n\t"
                  "s_nop 0\n\t"
@@ -155,7 +200,6 @@ __device__ __forceinline__ void glds_piece_off(uint32_t lane16, const char *gsrc
                  : "v"(lane16), "s"(gsrc), "s"(dst), "n"(OFF)
                  : "memory");
 #else
-    (void)keep;
     glds_piece(lane16, gsrc + OFF, dst + OFF);
 #endif
 }
@@ -237,10 +281,11 @@ __device__ __forceinline__ void load_bias(f32x16 &b, const LDS_AS float *bias, i
     }
 }
 
-// k-step of the NEXT tile behind whose MFMAs pair pr of a finished tile is converted: spread over steps 1 .. KS - 1 (not step
+// k-step of the NEXT tile behind whose MFMAs pair pr of a finished tile is converted: spread over steps 1 .. LAST (not step
 // 0: reading an accumulator right behind the MFMA that finished it costs the MFMA-write -> VALU-read wait states)
-template <int KS>
-constexpr int pair_step(int pr) { return 1 + pr * (KS - 1) / 8; }
+template <int LAST>
+constexpr int pair_step(int pr) { return LAST == 15 ? (pr == 0 ? 1 : 2 * pr) // 16-piece tiles: even steps, the DMA pieces go out on odd ones
+                                                    : 1 + pr * (LAST - 1) / 7; }
 
 #if NERF_BV2_SCHED_BARRIER
 #define BV2_PIN() __builtin_amdgcn_sched_barrier(0)
@@ -248,15 +293,19 @@ constexpr int pair_step(int pr) { return 1 + pr * (KS - 1) / 8; }
 #define BV2_PIN() ((void)0)
 #endif
 
+struct Acc { f32x16 a0, a1, b0, b1; }; // two accumulator sets x two sub-tiles; even output tiles use set a, odd ones set b
+
 // One output tile NTI of a layer: KS pieces from stream phase PH (piece index mod 16), 2 MFMAs per piece.  `bv` holds this
 // tile's bias (loaded one tile ahead) and is the C operand of the first MFMA pair; the next tile's bias is loaded into it
-// right after.  The previous tile's epilogue (p0, p1 -> out*[2 (NTI - 1)], [2 (NTI - 1) + 1]) is spread over the MFMA gaps:
-// pair pr at step pair_step(pr), sub-tile 0's half behind the first MFMA of the step, sub-tile 1's behind the second.
-template <int KS, int NT, int NTI, int PH, bool RELU_OUT, int HEAD>
-__device__ __forceinline__ void out_tile(const u32x4 (&in0)[KS], const u32x4 (&in1)[KS], u32x4 (&out0)[16], u32x4 (&out1)[16], f32x16 &c0,
-                                         f32x16 &c1, const f32x16 &p0, const f32x16 &p1, f32x16 &bv, const LDS_AS float *bias,
+// right after.  Under the MFMAs runs the epilogue of the previously finished tile (p0, p1), pair pr at step
+// pair_step<EP_LAST>(pr), sub-tile 0's half behind the first MFMA of the step, sub-tile 1's behind the second:
+//   EP = 1: the previous tile of this layer -> out*[2 (NTI - 1)], [2 (NTI - 1) + 1] (e* arguments);
+//   EP = 2: the LAST tile of the previous layer, whose packed result is k-steps PIDX, PIDX + 1 of this layer's own input:
+//           written into in*[PIDX], in*[PIDX + 1] before the MFMAs of step PIDX read them (EP_LAST < PIDX).
+template <int KS, int NT, int NTI, int PH, int EP, bool EP_RELU, int EP_HEAD, int EP_NTI, int EP_LAST>
+__device__ __forceinline__ void out_tile(const u32x4 (&in0)[KS], const u32x4 (&in1)[KS], u32x4 &e0a, u32x4 &e0b, u32x4 &e1a, u32x4 &e1b,
+                                         f32x16 &c0, f32x16 &c1, const f32x16 &p0, const f32x16 &p1, f32x16 &bv, const LDS_AS float *bias,
                                          const LDS_AS float *small, Heads &H, PipeV &P, int h) {
-    constexpr int o = (2 * (NTI > 0 ? NTI - 1 : 0)) & 15;
     static_for<0, KS>([&](auto ks_c) {
         constexpr int ks = decltype(ks_c)::value;
         constexpr int ph = (PH + ks) % 16;
@@ -264,46 +313,65 @@ __device__ __forceinline__ void out_tile(const u32x4 (&in0)[KS], const u32x4 (&i
         if constexpr (ks == 0) c0 = MFMA16(a, __builtin_bit_cast(bf16x8, in0[ks]), bv);
         else                   c0 = MFMA16(a, __builtin_bit_cast(bf16x8, in0[ks]), c0);
         BV2_PIN();
-        if constexpr (NTI > 0)
+        if constexpr (EP != 0)
             static_for<0, 8>([&](auto pr_c) {
                 constexpr int pr = decltype(pr_c)::value;
-                if constexpr (pair_step<KS>(pr) == ks) convert_half<pr, 0, RELU_OUT, HEAD, NTI - 1>(p0, out0[o], out0[o + 1], H, small, h);
+                if constexpr (pair_step<EP_LAST>(pr) == ks) convert_half<pr, 0, EP_RELU, EP_HEAD, EP_NTI>(p0, e0a, e0b, H, small, h);
             });
         pipe_dma<ph>(P);
         BV2_PIN();
         if constexpr (ks == 0) c1 = MFMA16(a, __builtin_bit_cast(bf16x8, in1[ks]), bv);
         else                   c1 = MFMA16(a, __builtin_bit_cast(bf16x8, in1[ks]), c1);
         BV2_PIN();
-        if constexpr (NTI > 0)
+        if constexpr (EP != 0)
             static_for<0, 8>([&](auto pr_c) {
                 constexpr int pr = decltype(pr_c)::value;
-                if constexpr (pair_step<KS>(pr) == ks) convert_half<pr, 1, RELU_OUT, HEAD, NTI - 1>(p1, out1[o], out1[o + 1], H, small, h);
+                if constexpr (pair_step<EP_LAST>(pr) == ks) convert_half<pr, 1, EP_RELU, EP_HEAD, EP_NTI>(p1, e1a, e1b, H, small, h);
             });
         if constexpr (ks == 1 && NTI + 1 < NT) load_bias(bv, bias, NTI + 1, h); // the first MFMA pair has consumed bv
         BV2_PIN();
     });
 }
 
-// One layer: NT output tiles, accumulators double-buffered (even tiles set A, odd tiles set B); the last tile's epilogue is
-// a tail burst.  Every layer starts at stream phase 0 (layers are whole chunks; viewdirs is padded).
-template <int KS, int NT, bool RELU_OUT, int HEAD>
-__device__ __forceinline__ void layer(const u32x4 (&in0)[KS], const u32x4 (&in1)[KS], u32x4 (&out0)[16], u32x4 (&out1)[16],
+// One layer: NT (even) output tiles, so every layer starts on accumulator set a and ends on set b.
+//   PEND:  the previous layer deferred its last tile's epilogue (in set b): it runs under this layer's tile 0 and lands in
+//          in*[PIDX], in*[PIDX + 1]; PEND_RELU is that layer's activation.
+//   DEFER: leave this layer's last tile to the next layer in the same way instead of a tail burst (not for the head layers,
+//          whose sums are needed right away).
+// Every layer starts at stream phase 0 (layers are whole chunks; viewdirs is padded).
+template <int KS, int NT, bool RELU_OUT, int HEAD, bool PEND, bool PEND_RELU, int PIDX, bool DEFER>
+__device__ __forceinline__ void layer(u32x4 (&in0)[KS], u32x4 (&in1)[KS], u32x4 (&out0)[16], u32x4 (&out1)[16], Acc &C,
                                       const LDS_AS float *bias, const LDS_AS float *small, Heads &H, PipeV &P, int h) {
-    f32x16 a0, a1, b0, b1, bv;
+    static_assert(NT % 2 == 0, "layers alternate two accumulator sets and must end on set b");
+    static_assert(!DEFER || HEAD == 0, "a deferred epilogue only converts");
+    f32x16 bv;
     load_bias(bv, bias, 0, h);
     static_for<0, NT>([&](auto nt_c) {
         constexpr int nt = decltype(nt_c)::value;
         constexpr int ph = (nt * KS) % 16;
-        if constexpr ((nt & 1) == 0) out_tile<KS, NT, nt, ph, RELU_OUT, HEAD>(in0, in1, out0, out1, a0, a1, b0, b1, bv, bias, small, H, P, h);
-        else                         out_tile<KS, NT, nt, ph, RELU_OUT, HEAD>(in0, in1, out0, out1, b0, b1, a0, a1, bv, bias, small, H, P, h);
+        constexpr int o = (2 * (nt > 0 ? nt - 1 : 0)) & 15;
+        if constexpr (nt == 0) {
+            if constexpr (PEND)
+                out_tile<KS, NT, 0, ph, 2, PEND_RELU, 0, 0, PIDX - 2>(in0, in1, in0[PIDX], in0[PIDX + 1], in1[PIDX], in1[PIDX + 1], C.a0, C.a1, C.b0,
+                                                                      C.b1, bv, bias, small, H, P, h);
+            else
+                out_tile<KS, NT, 0, ph, 0, false, 0, 0, 2>(in0, in1, out0[0], out0[1], out1[0], out1[1], C.a0, C.a1, C.b0, C.b1, bv, bias, small, H, P, h);
+        } else if constexpr ((nt & 1) == 0) {
+            out_tile<KS, NT, nt, ph, 1, RELU_OUT, HEAD, nt - 1, KS - 1>(in0, in1, out0[o], out0[o + 1], out1[o], out1[o + 1], C.a0, C.a1, C.b0, C.b1, bv,
+                                                                        bias, small, H, P, h);
+        } else {
+            out_tile<KS, NT, nt, ph, 1, RELU_OUT, HEAD, nt - 1, KS - 1>(in0, in1, out0[o], out0[o + 1], out1[o], out1[o + 1], C.b0, C.b1, C.a0, C.a1, bv,
+                                                                        bias, small, H, P, h);
+        }
     });
-    constexpr int o = (2 * (NT - 1)) & 15;
-    const f32x16 &l0 = ((NT - 1) & 1) ? b0 : a0, &l1 = ((NT - 1) & 1) ? b1 : a1;
-    static_for<0, 8>([&](auto pr_c) {
-        constexpr int pr = decltype(pr_c)::value;
-        convert_half<pr, 0, RELU_OUT, HEAD, NT - 1>(l0, out0[o], out0[o + 1], H, small, h);
-        convert_half<pr, 1, RELU_OUT, HEAD, NT - 1>(l1, out1[o], out1[o + 1], H, small, h);
-    });
+    if constexpr (!DEFER) {
+        constexpr int o = (2 * (NT - 1)) & 15;
+        static_for<0, 8>([&](auto pr_c) {
+            constexpr int pr = decltype(pr_c)::value;
+            convert_half<pr, 0, RELU_OUT, HEAD, NT - 1>(C.b0, out0[o], out0[o + 1], H, small, h);
+            convert_half<pr, 1, RELU_OUT, HEAD, NT - 1>(C.b1, out1[o], out1[o + 1], H, small, h);
+        });
+    }
 }
 
 } // namespace
@@ -370,34 +438,35 @@ __global__ __launch_bounds__(256, 1) void nerf_mlp_kernel_bf16v2(const MlpArgs A
             float px, py, pz;
             f32x16 E[2];
             point_of<MODE>(A, in0, px, py, pz);
-            encode_point<true>(px, py, pz, h, E);
+            ENCODE_POINT(px, py, pz, h, E);
             pack_tile(E[0], E0[0], E0[1]); pack_tile(E[1], E0[2], E0[3]);
             point_of<MODE>(A, in1, px, py, pz);
-            encode_point<true>(px, py, pz, h, E);
+            ENCODE_POINT(px, py, pz, h, E);
             pack_tile(E[0], E1[0], E1[1]); pack_tile(E[1], E1[2], E1[3]);
         }
         u32x4 X0[16], X1[16], Y0[16], Y1[16];
+        Acc C;
         Heads H;
         H.alpha[0] = H.alpha[1] = 0.f;
 #pragma unroll
         for (int c = 0; c < 3; ++c) H.rgb[0][c] = H.rgb[1][c] = 0.f;
 
-        layer<4, 8, true, 0>(E0, E1, X0, X1, small + kBiasOff + 0 * 256, small, H, P, h);   // dense0 (src/network.rs:204)
-        layer<16, 8, true, 0>(X0, X1, Y0, Y1, small + kBiasOff + 1 * 256, small, H, P, h);
-        layer<16, 8, true, 0>(Y0, Y1, X0, X1, small + kBiasOff + 2 * 256, small, H, P, h);
-        layer<16, 8, true, 0>(X0, X1, Y0, Y1, small + kBiasOff + 3 * 256, small, H, P, h);
-        layer<16, 8, true, 0>(Y0, Y1, X0, X1, small + kBiasOff + 4 * 256, small, H, P, h);
+        layer<4, 8, true, 0, false, false, 0, true>(E0, E1, X0, X1, C, small + kBiasOff + 0 * 256, small, H, P, h);   // dense0 (src/network.rs:204)
+        layer<16, 8, true, 0, true, true, 14, true>(X0, X1, Y0, Y1, C, small + kBiasOff + 1 * 256, small, H, P, h);
+        layer<16, 8, true, 0, true, true, 14, true>(Y0, Y1, X0, X1, C, small + kBiasOff + 2 * 256, small, H, P, h);
+        layer<16, 8, true, 0, true, true, 14, true>(X0, X1, Y0, Y1, C, small + kBiasOff + 3 * 256, small, H, P, h);
+        layer<16, 8, true, 0, true, true, 14, true>(Y0, Y1, X0, X1, C, small + kBiasOff + 4 * 256, small, H, P, h);
         {   // dense5 on [encoding (4 k-steps) ; h4 (16 k-steps)] (src/network.rs:209-210)
             u32x4 C0[20], C1[20];
 #pragma unroll
             for (int k = 0; k < 4; ++k) { C0[k] = E0[k]; C1[k] = E1[k]; }
 #pragma unroll
             for (int k = 0; k < 16; ++k) { C0[4 + k] = X0[k]; C1[4 + k] = X1[k]; }
-            layer<20, 8, true, 0>(C0, C1, Y0, Y1, small + kBiasOff + 5 * 256, small, H, P, h);
+            layer<20, 8, true, 0, true, true, 18, true>(C0, C1, Y0, Y1, C, small + kBiasOff + 5 * 256, small, H, P, h); // h4's last tile lands in C*[18], [19]
         }
-        layer<16, 8, true, 0>(Y0, Y1, X0, X1, small + kBiasOff + 6 * 256, small, H, P, h);
+        layer<16, 8, true, 0, true, true, 14, true>(Y0, Y1, X0, X1, C, small + kBiasOff + 6 * 256, small, H, P, h);
         // dense7: alpha head from the f32 accumulators; the packed h8 is only needed when the colour branch follows
-        layer<16, 8, true, FULL ? 1 : 2>(X0, X1, Y0, Y1, small + kBiasOff + 7 * 256, small, H, P, h);
+        layer<16, 8, true, FULL ? 1 : 2, true, true, 14, false>(X0, X1, Y0, Y1, C, small + kBiasOff + 7 * 256, small, H, P, h);
         const float s0 = fmaxf(xhalf_sum(H.alpha[0]) + small[kMiscOff + 0], 0.f); // ReLU(alpha) (src/network.rs:216)
         const float s1 = fmaxf(xhalf_sum(H.alpha[1]) + small[kMiscOff + 0], 0.f);
         if (h == 0) {
@@ -419,16 +488,16 @@ __global__ __launch_bounds__(256, 1) void nerf_mlp_kernel_bf16v2(const MlpArgs A
                     continue;
                 }
             }
-            layer<16, 8, false, 0>(Y0, Y1, X0, X1, small + kBiasOff + 8 * 256, small, H, P, h); // bottleneck: no activation (:218)
+            layer<16, 8, false, 0, false, false, 0, true>(Y0, Y1, X0, X1, C, small + kBiasOff + 8 * 256, small, H, P, h); // bottleneck: no activation (:218)
             u32x4 V0[18], V1[18];
 #pragma unroll
             for (int k = 0; k < 16; ++k) { V0[k] = X0[k]; V1[k] = X1[k]; }
             {
                 f32x16 D;
-                encode_dir<true>(in0.dx, in0.dy, in0.dz, h, D); pack_tile(D, V0[16], V0[17]);
-                encode_dir<true>(in1.dx, in1.dy, in1.dz, h, D); pack_tile(D, V1[16], V1[17]);
+                ENCODE_DIR(in0.dx, in0.dy, in0.dz, h, D); pack_tile(D, V0[16], V0[17]);
+                ENCODE_DIR(in1.dx, in1.dy, in1.dz, h, D); pack_tile(D, V1[16], V1[17]);
             }
-            layer<18, 4, true, 3>(V0, V1, Y0, Y1, small + kBiasViewOff, small, H, P, h); // viewdirs + rgb partial sums (:220-223)
+            layer<18, 4, true, 3, true, false, 14, false>(V0, V1, Y0, Y1, C, small + kBiasViewOff, small, H, P, h); // viewdirs + rgb partial sums (:220-223)
             {   // viewdirs' 72 pieces end at phase 8; the stream carries 8 zero pieces up to the chunk end: step over them
                 bf16x8 d;
                 d = pipe_take<8>(P);                   asm volatile("" ::"v"(d));

@@ -385,9 +385,27 @@ def test_bf16_forward_matches_bf16_emulation(renderer, oracle_nets):
         assert 1e-3 < d32.max() < 0.5                      # really is bf16, and not garbage
     again = renderer.fine.forward_batch(g["pts"], g["dirs"], dtype="bf16")
     assert np.array_equal(again[1], sg) and np.array_equal(again[0], rgb)
-    for n in (1, 33, 129):
+    for n in (1, 33, 129, 255, 256, 257, 511, 1000):       # ragged workgroup tiles (256 points) and sub-tiles (32)
         r2, s2 = renderer.fine.forward_batch(g["pts"][:, :n], g["dirs"][:n], dtype="bf16")
         assert np.array_equal(s2, sg[:n]) and np.array_equal(r2, rgb[:n])
+
+
+def test_bf16_both_kernel_designs_agree(renderer, native):
+    """The two bf16 kernels (mlp_kernel_bf16v2.hip = default, mlp_kernel_bf16.hip via NERF_BF16_KERNEL=v1) implement the same
+    arithmetic over differently ordered weight streams; v2 builds its encodings by angle doubling (<= 2e-6 absolute before
+    the bf16 rounding), so single bf16 rounding flips may differ, nothing else."""
+    g = golden("forward_batch_4096.npz")
+    rgb2, sg2 = renderer.fine.forward_batch(g["pts"], g["dirs"], dtype="bf16")
+    os.environ["NERF_BF16_KERNEL"] = "v1"
+    try:
+        with native.Renderer(0) as r1:
+            r1.load_scene(SCENE)
+            rgb1, sg1 = r1.fine.forward_batch(g["pts"], g["dirs"], dtype="bf16")
+    finally:
+        del os.environ["NERF_BF16_KERNEL"]
+    ds = np.abs(sg2 - sg1) / (1 + np.abs(sg1)); dr = np.abs(rgb2 - rgb1)
+    assert np.quantile(ds, 0.99) <= 1e-4 and ds.mean() <= 1e-3 and ds.max() <= 0.1
+    assert np.quantile(dr, 0.99) <= 1e-4 and dr.mean() <= 1e-4 and dr.max() <= 0.05
 
 
 def test_bf16_render_gate2(renderer, native, samples):
