@@ -102,6 +102,9 @@ def main():
     ap.add_argument("--skip-empty", action="store_true",
                     help="SURVEY 8f.2 (reported separately, not the headline): skip the colour head of all-empty tiles; "
                          "the image is bit-identical, the roofline line then prices EXECUTED flops")
+    ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
+                    help="N > 1: strong = ONE frame split in row bands + one RCCL all-gather (SURVEY 8e, default); weak = every rank "
+                         "renders a whole frame of its own view (independent frames of a camera path, no data-path collective)")
     ap.add_argument("--no-extra", action="store_true", help="skip the separately reported skip_empty frames (profiling runs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-naive", action="store_true", help="also time the reference's own loop order (minutes)")
@@ -136,9 +139,12 @@ def main():
     stream = torch.cuda.current_stream(dev).cuda_stream
     frame = torch.empty((args.height, args.width, 3), dtype=torch.float32, device=dev)
 
+    weak = args.scaling == "weak" and world > 1
+    view_seed = args.seed + (rank if weak else 0)  # weak scaling: rank r renders view r (its own sample-jitter stream)
+
     def step():
-        if not use_dist:
-            N.render_image(r.coarse, r.fine, cam, args.fine, seed=args.seed, ssaa=args.ssaa, dtype=args.dtype,
+        if not use_dist or weak:
+            N.render_image(r.coarse, r.fine, cam, args.fine, seed=view_seed, ssaa=args.ssaa, dtype=args.dtype,
                            skip_empty=args.skip_empty, device_out=frame.data_ptr(), stream=stream)
             return frame
         return N.render_image_distributed(r.coarse, r.fine, cam, args.fine, seed=args.seed, ssaa=args.ssaa, dtype=args.dtype,
@@ -193,23 +199,24 @@ def main():
         flop_ray = N.flop_per_ray(args.coarse, args.fine)
         bf16 = args.dtype == "bf16"
         peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_FP32_MFMA_TFLOPS
-        value = n_rays * args.steps / dt
+        value = n_rays * args.steps * (world if weak else 1) / dt  # whole-job rays/s over all ranks
         # executed flops of the dominant launches: a skipped sample still runs dense0..7 + alpha (sigma-only cost)
         flops_dom = pts_dom * N.FLOP_PER_POINT_FULL - n_dom * skipped_per_launch * (N.FLOP_PER_POINT_FULL - N.FLOP_PER_POINT_SIGMA)
         ach = flops_dom / (ms_dom * 1e-3) / 1e12 if ms_dom > 0 else 0.0
         line = {  # noqa: E501
             "metric": "rays/sec, lego 800x800 (64 coarse + 128 fine samples per ray)", "value": value, "unit": "rays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "weak" if weak else "strong", "vs_baseline": None,
             "dtype": "bf16 operands / f32 accumulate (C5 study, PSNR-level parity)" if bf16 else "f32",
             "data": "real lego weights (lego_rust/, 2 x 595,844 f32 parameters) + tf_reference_samples.json camera; "
                     "sample positions from the seeded counter RNG (no dataset involved)",
             "config": {"workload": (f"C5-style: {args.ssaa}x{args.ssaa} SSAA, bf16 MLP, " if bf16 or args.ssaa > 1 else "C3: ") +
                                    f"lego coarse+fine hierarchical, {args.width}x{args.height}, {args.coarse}+{args.fine} "
-                                   f"samples/ray, {args.dtype}, {world}xMI355X" + (", row bands + RCCL all-gather" if world > 1 else ""),
+                                   f"samples/ray, {args.dtype}, {world}xMI355X" +
+                                   ("" if world == 1 else ", one frame per rank, no collective" if weak else ", row bands + RCCL all-gather"),
                        "rays_per_step": n_rays, "flop_per_ray": flop_ray, "seed": args.seed,
                        "skip_empty": bool(args.skip_empty), "colour_head_skipped_samples_per_frame": skipped_per_launch,
-                       "whole_job_fraction_of_mfma_roofline": value * flop_ray / (world * peak * 1e12)},
+                       "whole_job_fraction_of_mfma_roofline": value * flop_ray / (world * peak * 1e12)},  # per-GPU average
             "roofline": {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
                          "frac": ach / peak, "traffic": None if bf16 else pmc_traffic_bytes(),
                          "kernel": (("nerf_mlp_kernel_bf16" if os.environ.get("NERF_BF16_KERNEL") == "v1" else "nerf_mlp_kernel_bf16v2") if bf16

@@ -2,6 +2,7 @@
 """Condense gpurun_out/prof_<tag>/ (rocprofv3 csv output) into profiles/<tag>_*.{csv,md}."""
 import collections, csv, os, shutil, sys
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+extra = sys.argv[2] if len(sys.argv) > 2 else ""  # extra bench.py arguments the profile was taken with
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
 dst = os.path.join(ROOT, "profiles")
@@ -27,8 +28,8 @@ with open(os.path.join(dst, f"{tag}_pmc_summary.csv"), "w") as out:
     out.write("kernel,dispatches,ms_under_pmc," + ",".join(names) + "\n")
     for k, v in agg.items():
         out.write(f"\"{k}\",{calls[k]},{dur[k]:.3f}," + ",".join(f"{v.get(n, 0):.6g}" for n in names) + "\n")
-lines = [f"# rocprofv3 summary {tag}", "", "Command: `rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extra` and",
-         "separate `--pmc` passes (`bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extra`), MI355X, 800x800, 64+128 samples.", "", "## kernel-trace stats", "", "```"]
+lines = [f"# rocprofv3 summary {tag}", "", "Command: `rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extra" + (" " + extra if extra else "") + "` and",
+         "separate `--pmc` passes (`bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extra" + (" " + extra if extra else "") + "`), MI355X, 800x800, 64+128 samples.", "", "## kernel-trace stats", "", "```"]
 lines += open(os.path.join(dst, f"{tag}_kernel_stats.csv")).read().strip().split("\n") + ["```", "", "## derived (PMC pass, one frame)", ""]
 for k, v in agg.items():
     if "nerf_mlp_kernel" not in k or not v.get("SQ_VALU_MFMA_BUSY_CYCLES"):
@@ -38,7 +39,7 @@ for k, v in agg.items():
     busy = v["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024 / (v["GRBM_GUI_ACTIVE"] / 8)
     wave = v["SQ_WAVE_CYCLES"]
     lines.append(f"* `{k}`: {dur[k]:.1f} ms under PMC; effective clock {clk:.2f} GHz (GRBM_GUI_ACTIVE/8/t); MFMA pipe busy "
-                 f"{100 * busy:.1f} % of cycles (SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs = 64 x #MFMA); of the wave cycles "
+                 f"{100 * busy:.1f} % of cycles (SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs; one f32 32x32x2 MFMA = 64 busy cycles, one bf16 32x32x16 = 32); of the wave cycles "
                  f"{100 * v['SQ_WAIT_ANY'] / wave:.1f} % waitcnt/barrier (SQ_WAIT_ANY), {100 * v['SQ_WAIT_INST_ANY'] / wave:.1f} % issue stall "
                  f"(SQ_WAIT_INST_ANY, i.e. waiting for the matrix pipe), {100 * v['SQ_ACTIVE_INST_ANY'] / wave:.1f} % issuing; "
                  f"HBM traffic FETCH_SIZE x2 (gfx950 correction) = {2 * v.get('FETCH_SIZE', 0) / 1024:.1f} MB, WRITE_SIZE = {v.get('WRITE_SIZE', 0) / 1024:.1f} MB "
