@@ -14,7 +14,7 @@
 // * alpha (dense7) and rgb (viewdirs) heads accumulate in f32 from the f32 accumulators inside those epilogues, so the
 //   arithmetic is exactly v1's (and the oracle emulation's): bf16 operands, f32 accumulate, f32 heads.
 // Weight stream (host_util.cpp pack_network_bf16_v2): per layer, per output tile, per k-step one 1-KiB piece; 16-KiB chunks
-// of 16 pieces; 60 chunks for the sigma layers, 73 for all (viewdirs' 72 pieces zero-padded to 80); 3-slot ring; sync at
+// of 16 pieces; 60 chunks for the sigma layers, 73 for all (viewdirs' 72 pieces zero-padded to 80); ring of kRingSlotsBf16V2 slots; sync at
 // piece 8 of every chunk; each wave DMA's one piece at pieces 9, 11, 13, 15.  All layers start at chunk boundaries.
 #include <hip/hip_runtime.h>
 #include <stdint.h>

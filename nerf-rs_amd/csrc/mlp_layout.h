@@ -65,7 +65,7 @@ constexpr int kLdsBytesBf16 = kRingSlotsBf16 * kChunkBytesBf16 + kSmallBytes;
 // (+ 8 zero pieces so that the stream ends on a chunk boundary).  64 points per wave, 256 per workgroup.
 constexpr int kChunkBytesBf16V2 = 16384;
 #ifndef NERF_BV2_RING_SLOTS
-#define NERF_BV2_RING_SLOTS 6
+#define NERF_BV2_RING_SLOTS 3
 #endif
 constexpr int kRingSlotsBf16V2 = NERF_BV2_RING_SLOTS; // 3..8: chunk c + kRingSlots - 1 is DMA'd while chunk c is consumed (a chunk lasts ~0.45 us)
 constexpr int kChunksSigmaBf16V2 = (32 + 4 * 128 + 160 + 2 * 128) / 16; // 60

@@ -28,6 +28,7 @@ struct ResampleArgs {
     float *w_out;                // n_rays x nc
     float *cdf_out;              // n_rays x (nc - 1)
     float *t_new_out;            // n_rays x nf (unsorted draws)
+    int sort_pow2 = 0;           // set by launch_resample: smallest power of two >= nc + nf (bitonic sort width)
 };
 
 struct CompositeArgs {

@@ -9,8 +9,8 @@
 // All arithmetic is IEEE f32 without contraction (the file is built with -ffp-contract=off and HIP's default
 // correctly-rounded fp32 divide/sqrt), so ray directions and coarse sample positions are BIT-IDENTICAL to the
 // CPU path; the sequential f32 sums of the reference (pdf sum, cdf, transmittance, colour accumulation) are kept
-// in the reference's order.  These kernels are HBM/latency-bound bookkeeping (<1 % of a frame); the layout is one
-// wave per ray (lanes = samples), 4 rays per 256-thread workgroup.
+// in the reference's order.  These kernels are HBM/latency-bound bookkeeping (<1 % of an f32 frame): resampling runs one
+// wave per ray (lanes = samples), compositing one ray per lane with LDS-staged samples.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -88,16 +88,18 @@ __global__ void k_stratified(RayGenArgs a, int count, float near_, float far_, u
 // alpha[] in LDS -> w[] in LDS, sequential in sample order exactly as compute_weights (src/lib.rs:261-280).
 // Executed redundantly by every lane of the wave (wave-uniform control flow, LDS broadcast reads).
 __device__ __forceinline__ void weights_scan(const float *alpha, float *w, int n, int lane) {
+    // branch-free form of the early break (src/lib.rs:273-279): once T < 1e-4 every later weight is 0 and T is not touched
+    // again -- identical values, but the loop has no loop-carried branch, so the LDS reads pipeline
     float T = 1.0f;
-    int i = 0;
-    for (; i < n; ++i) {
+    bool cut = false;
+#pragma unroll 8
+    for (int i = 0; i < n; ++i) {
         const float al = alpha[i];
-        const float wi = T * al;
+        const float wi = cut ? 0.0f : T * al;
         if (lane == 0) w[i] = wi;
-        T *= 1.0f - al;
-        if (T < 1e-4f) { ++i; break; }
+        T = cut ? T : T * (1.0f - al);
+        cut = cut || T < 1e-4f;
     }
-    for (int k = i + lane; k < n; k += 64) w[k] = 0.0f; // weights.extend(repeat(0.0)) :277
 }
 
 __device__ __forceinline__ float sample_alpha(const float *t, const float *sigma, int i, int n, float far_) {
@@ -107,14 +109,14 @@ __device__ __forceinline__ float sample_alpha(const float *t, const float *sigma
 }
 
 // ---- hierarchical resampling: one wave per ray --------------------------------------------------------
-// LDS per wave (floats): t[nc] sigma[nc] alpha[nc] w[nc] cdf[nc] bins[nc] merged[nc+nf]
+// LDS per wave (floats): t[nc] sigma[nc] alpha[nc] w[nc] cdf[nc] bins[nc] merged[pow2 >= nc+nf]
 __global__ __launch_bounds__(256) void k_resample(ResampleArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds_f[];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int ray = blockIdx.x * 4 + wv;
     if (ray >= a.n_rays) return; // whole wave exits together; no block-level barrier below
     const int nc = a.nc, nf = a.nf, M = nc + nf;
-    float *t = lds_f + (size_t)wv * (6 * nc + M);
+    float *t = lds_f + (size_t)wv * (6 * nc + a.sort_pow2);
     float *sg = t + nc, *alpha = sg + nc, *w = alpha + nc, *cdf = w + nc, *bins = cdf + nc, *mg = bins + nc;
 
     for (int i = lane; i < nc; i += 64) { t[i] = a.t_coarse[(size_t)ray * nc + i]; sg[i] = a.sigma_coarse[(size_t)ray * nc + i]; }
@@ -162,42 +164,104 @@ __global__ __launch_bounds__(256) void k_resample(ResampleArgs a) {
     wave_sync();
     if (a.t_new_out) for (int s = lane; s < nf; s += 64) a.t_new_out[(size_t)ray * nf + s] = mg[nc + s];
 
-    // merged.sort_by(partial_cmp) (:419): rank sort, ties broken by original index (stable)
-    for (int e = lane; e < M; e += 64) {
-        const float v = mg[e];
-        int rank = 0;
-        for (int j = 0; j < M; ++j) { const float x = mg[j]; rank += (x < v || (x == v && j < e)) ? 1 : 0; }
-        a.t_fine[(size_t)ray * M + rank] = v;
+    // merged.sort_by(partial_cmp) (:419).  Only the sorted VALUES leave this kernel and equal floats are interchangeable, so any
+    // correct sort reproduces the reference's stable sort bit for bit: a bitonic network over the next power of two (pad =
+    // +inf), two compare-exchanges per lane and step, in LDS (36 steps for 192 -> 256 instead of 192 compares per element).
+    const int P = a.sort_pow2;
+    for (int e = M + lane; e < P; e += 64) mg[e] = __builtin_inff();
+    wave_sync();
+    for (int k = 2; k <= P; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int p = lane; p < (P >> 1); p += 64) {
+                const int i = ((p & ~(j - 1)) << 1) | (p & (j - 1)), l = i | j;
+                const float x = mg[i], y = mg[l];
+                const bool up = (i & k) == 0;
+                const float lo = fminf(x, y), hi = fmaxf(x, y);
+                mg[i] = up ? lo : hi; mg[l] = up ? hi : lo;
+            }
+            wave_sync();
+        }
     }
+    for (int e = lane; e < M; e += 64) a.t_fine[(size_t)ray * M + e] = mg[e];
 }
 
-// ---- compositing: one wave per ray -------------------------------------------------------------------
-// LDS per wave (floats): t[n] sigma[n] alpha[n] w[n] rgb[3n]
-__global__ __launch_bounds__(256) void k_composite(CompositeArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float lds_f[];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int ray = blockIdx.x * 4 + wv;
-    if (ray >= a.n_rays) return;
+// ---- compositing: one ray per lane, samples staged through LDS ------------------------------------------
+// integrate_ray (src/lib.rs:176-195) is a sequential recurrence per ray (transmittance product with the T < 1e-4 cut, colour
+// sums in sample order), so a lane owns a ray and walks its samples in order -- the arithmetic and its order are exactly
+// the reference's.  A wave = 64 consecutive rays.  Global reads stay line-granular: the wave stages kCompChunk (16)
+// samples of its 64 rays at a time in LDS (16 consecutive floats of t / sigma = one 64-B line per ray, 48 floats of rgb =
+// three lines), rows padded to odd strides so that the per-lane walk is bank-conflict free.  One wave per workgroup:
+// 21 KiB of LDS each, seven workgroups per CU.
+constexpr int kCompChunk = 16;
+constexpr int kCompTS = kCompChunk + 1;     // row strides (floats)
+constexpr int kCompCS = 3 * kCompChunk + 1;
+
+__global__ __launch_bounds__(64) void k_composite(CompositeArgs a) {
+    __shared__ float s_t[64 * kCompTS], s_sg[64 * kCompTS], s_col[64 * kCompCS];
+    const int lane = threadIdx.x;
+    const int ray0 = blockIdx.x * 64;
     const int n = a.n;
-    float *t = lds_f + (size_t)wv * (7 * n);
-    float *sg = t + n, *alpha = sg + n, *w = alpha + n, *col = w + n;
-    for (int i = lane; i < n; i += 64) { t[i] = a.t[(size_t)ray * n + i]; sg[i] = a.sigma[(size_t)ray * n + i]; }
-    for (int i = lane; i < 3 * n; i += 64) col[i] = a.rgb[(size_t)ray * 3 * n + i];
-    wave_sync();
-    for (int i = lane; i < n; i += 64) alpha[i] = sample_alpha(t, sg, i, n, a.far_);
-    wave_sync();
-    weights_scan(alpha, w, n, lane);
-    wave_sync();
-    if (a.w_out) for (int i = lane; i < n; i += 64) a.w_out[(size_t)ray * n + i] = w[i];
-    float r = 0.0f, g = 0.0f, b = 0.0f, acc = 0.0f; // integrate_ray :185-194, sample order
-    for (int i = 0; i < n; ++i) {
-        const float wi = w[i];
-        r += col[3 * i] * wi; g += col[3 * i + 1] * wi; b += col[3 * i + 2] * wi;
-        acc += wi;
+    const int my_ray = ray0 + lane;
+    const bool live = my_ray < a.n_rays;
+    const int sub = lane & 15, rq = lane >> 4; // staging: 4 rays x 16 samples per wave-instruction
+    float T = 1.0f, r = 0.0f, g = 0.0f, b = 0.0f, acc = 0.0f;
+    bool cut = false;                           // compute_weights' early break (src/lib.rs:273-279): later weights are 0
+    float t_cur = 0.0f;
+    for (int c0 = 0; c0 < n; c0 += kCompChunk) {
+        const int cs = n - c0 < kCompChunk ? n - c0 : kCompChunk;
+        // stage: t[c0 .. c0+cs] (one extra: the next sample's t closes the last interval), sigma, rgb.  All loads are issued
+        // before the first LDS store and none is predicated (indices are clamped instead; a clamped slot is never read):
+        // a guarded load would sit in its own basic block behind its own s_waitcnt and serialise the memory latency.
+        float vt[16], vs[16], vc[16][3];
+        const int se = sub < cs ? sub : cs - 1;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            int gr = ray0 + 4 * k + rq; gr = gr < a.n_rays ? gr : a.n_rays - 1;
+            const size_t base = (size_t)gr * n + c0;
+            vt[k] = a.t[base + se]; vs[k] = a.sigma[base + se];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const int e = 16 * q + sub;
+                vc[k][q] = a.rgb[3 * base + (e < 3 * cs ? e : 3 * cs - 1)];
+            }
+        }
+        int er = my_ray < a.n_rays ? my_ray : a.n_rays - 1;
+        const float t_ext = (c0 + cs < n) ? a.t[(size_t)er * n + c0 + cs] : a.far_; // last interval ends at far (:180)
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int rr = 4 * k + rq;
+            s_t[rr * kCompTS + se] = vt[k]; s_sg[rr * kCompTS + se] = vs[k];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const int e = 16 * q + sub;
+                s_col[rr * kCompCS + (e < 3 * cs ? e : 3 * cs - 1)] = vc[k][q];
+            }
+        }
+        s_t[lane * kCompTS + cs] = t_ext; // slot cs is written by nobody else (clamped duplicates land on slots < cs)
+        __syncthreads();
+        if (c0 == 0) t_cur = s_t[lane * kCompTS];
+        for (int i = 0; i < cs; ++i) {
+            const float t_next = s_t[lane * kCompTS + i + 1];
+            float delta = t_next - t_cur;              // sample_alpha
+            if (delta < 0.0f) delta = 0.0f;
+            const float al = 1.0f - expf(-s_sg[lane * kCompTS + i] * delta);
+            t_cur = t_next;
+            float wi = 0.0f;
+            if (!cut) {
+                wi = T * al;
+                T *= 1.0f - al;
+                cut = T < 1e-4f;
+            }
+            if (a.w_out && live) a.w_out[(size_t)my_ray * n + c0 + i] = wi;
+            const float *col = &s_col[lane * kCompCS + 3 * i];
+            r += col[0] * wi; g += col[1] * wi; b += col[2] * wi; // integrate_ray :185-194, sample order
+            acc += wi;
+        }
+        __syncthreads();
     }
-    if (lane == 0) {
+    if (live) {
         const float bg = 1.0f * (1.0f - acc);
-        float *o = a.out + 3 * (size_t)ray;
+        float *o = a.out + 3 * (size_t)my_ray;
         o[0] = r + bg; o[1] = g + bg; o[2] = b + bg;
     }
 }
@@ -230,24 +294,26 @@ hipError_t launch_stratified(const RayGenArgs &a, int count, float near_, float 
     return hipGetLastError();
 }
 
-size_t resample_lds_bytes(int nc, int nf) { return (size_t)4 * (6 * nc + nc + nf) * sizeof(float); }
-size_t composite_lds_bytes(int n) { return (size_t)4 * 7 * n * sizeof(float); }
+static int pow2_at_least(int v) { int p = 2; while (p < v) p <<= 1; return p; }
+size_t resample_lds_bytes(int nc, int nf) { return (size_t)4 * (6 * nc + pow2_at_least(nc + nf)) * sizeof(float); }
+size_t composite_lds_bytes(int) { return sizeof(float) * 64 * (2 * kCompTS + kCompCS); } // static, independent of n
 
 hipError_t sampling_init(void) {
     hipError_t e = hipFuncSetAttribute((const void *)k_resample, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return e;
-    return hipFuncSetAttribute((const void *)k_composite, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    return e;
 }
 
 hipError_t launch_resample(const ResampleArgs &a, hipStream_t st) {
     if (a.n_rays <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_resample, dim3((a.n_rays + 3) / 4), dim3(256), resample_lds_bytes(a.nc, a.nf), st, a);
+    ResampleArgs b = a;
+    b.sort_pow2 = pow2_at_least(a.nc + a.nf);
+    hipLaunchKernelGGL(k_resample, dim3((a.n_rays + 3) / 4), dim3(256), resample_lds_bytes(a.nc, a.nf), st, b);
     return hipGetLastError();
 }
 
 hipError_t launch_composite(const CompositeArgs &a, hipStream_t st) {
     if (a.n_rays <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_composite, dim3((a.n_rays + 3) / 4), dim3(256), composite_lds_bytes(a.n), st, a);
+    hipLaunchKernelGGL(k_composite, dim3((a.n_rays + 63) / 64), dim3(64), 0, st, a);
     return hipGetLastError();
 }
 
