@@ -22,19 +22,19 @@ PEAK_FP32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, "Peak F
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # same table, "Peak BF16/FP16 MFMA ~2.5 PF dense"
 
 
-def pmc_traffic_bytes():
+def pmc_traffic_bytes(kernel_prefix="void nerf_mlp_kernel<true"):
     """HBM bytes per launch of the fine-MLP kernel from the committed rocprofv3 PMC passes (profiles/*_pmc_summary.csv:
     separate FETCH_SIZE / WRITE_SIZE runs; FETCH_SIZE doubled per the gfx950 note in MI355X_MICROARCH.md).  The kernel is
-    MFMA-bound; this is reported for completeness (algorithmic: 20 B/point in+out = 2.46 GB per 122.88 M-point launch)."""
+    MFMA-bound; this is reported for completeness (algorithmic: 20 B/point in+out = 2.46 GB per 122.88 M-point launch).
+    The newest summary that holds the kernel wins."""
     import csv
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.csv")))
-    if not files:
-        return None
-    for row in csv.DictReader(open(files[-1])):
-        if row["kernel"].startswith("void nerf_mlp_kernel<true") and float(row.get("FETCH_SIZE", 0)) > 0:
-            n = max(int(row["dispatches"]), 1)
-            return (2.0 * float(row["FETCH_SIZE"]) + float(row["WRITE_SIZE"])) * 1024.0 / n
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.csv")), key=os.path.getmtime, reverse=True)
+    for f in files:
+        for row in csv.DictReader(open(f)):
+            if row["kernel"].startswith(kernel_prefix) and float(row.get("FETCH_SIZE", 0) or 0) > 0:
+                n = max(int(row["dispatches"]), 1)
+                return (2.0 * float(row["FETCH_SIZE"]) + float(row.get("WRITE_SIZE", 0) or 0)) * 1024.0 / n
     return None
 
 
@@ -218,7 +218,8 @@ def main():
                        "skip_empty": bool(args.skip_empty), "colour_head_skipped_samples_per_frame": skipped_per_launch,
                        "whole_job_fraction_of_mfma_roofline": value * flop_ray / (world * peak * 1e12)},  # per-GPU average
             "roofline": {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
-                         "frac": ach / peak, "traffic": None if bf16 else pmc_traffic_bytes(),
+                         "frac": ach / peak, "traffic": pmc_traffic_bytes(("void nerf_mlp_kernel_bf16<true" if os.environ.get("NERF_BF16_KERNEL") == "v1"
+                                                        else "void nerf_mlp_kernel_bf16v2<true") if bf16 else "void nerf_mlp_kernel<true"),
                          "kernel": (("nerf_mlp_kernel_bf16" if os.environ.get("NERF_BF16_KERNEL") == "v1" else "nerf_mlp_kernel_bf16v2") if bf16
                                     else "nerf_mlp_kernel") + "<FULL=true, MODE_RAYS> (fine network)",
                          "launches": n_dom, "avg_launch_ms": ms_dom / max(n_dom, 1),
