@@ -65,11 +65,13 @@ typedef struct {
     int32_t ssaa;         /* ext: s x s rays per pixel, box filter; 0 or 1 => off */
     uint64_t seed;        /* counter-RNG seed (reference: unseeded thread_rng, src/lib.rs:375,407) */
     int32_t mlp_dtype;    /* ext: NERF_MLP_F32 (0, default: exact-f32 MFMA, the parity path) or NERF_MLP_BF16 (1: bf16
-                           * operands / f32 accumulate on the bf16 matrix cores -- BASELINE config C5; PSNR-level parity) */
+                           * operands / f32 accumulate on the bf16 matrix cores -- BASELINE config C5; PSNR-level parity).
+                           * Environment, read by nerf_create: NERF_BF16_KERNEL=v1 selects the first of the two bf16 kernel
+                           * designs (A/B runs; same arithmetic) */
     int32_t skip_empty;   /* ext: 1 = skip the colour head (bottleneck + viewdirs + rgb, 17 % of a full MLP
-                           * evaluation) for every 128-sample tile whose densities are all 0.  EXACT: such samples have
-                           * alpha = 0 and weight 0, the image is bit-identical; only the work changes.  Default 0 so that
-                           * timings are plain executed-FLOP figures. */
+                           * evaluation) for every workgroup tile (128 samples in f32, 256 in bf16) whose densities are all 0.
+                           * EXACT: such samples have alpha = 0 and weight 0, the image is bit-identical; only the work
+                           * changes.  Default 0 so that timings are plain executed-FLOP figures. */
     int32_t reserved[2];  /* must be 0 */
 } nerf_render_opts;
 
