@@ -43,7 +43,7 @@ typedef enum {
 } nerf_status;
 
 enum { NERF_NET_COARSE = 0, NERF_NET_FINE = 1 };
-enum { NERF_MLP_F32 = 0, NERF_MLP_BF16 = 1 };
+enum { NERF_MLP_F32 = 0, NERF_MLP_BF16 = 1, NERF_MLP_BF16X3 = 2 };
 
 /* Mirrors `struct Camera` (src/lib.rs:197-211); samples_per_ray lives in nerf_render_opts.n_coarse.
  * alpha_* are the half field-of-view angles (radians); dir/up need not be orthogonal (basis is rebuilt
@@ -67,7 +67,10 @@ typedef struct {
     int32_t mlp_dtype;    /* ext: NERF_MLP_F32 (0, default: exact-f32 MFMA, the parity path) or NERF_MLP_BF16 (1: bf16
                            * operands / f32 accumulate on the bf16 matrix cores -- BASELINE config C5; PSNR-level parity).
                            * Environment, read by nerf_create: NERF_BF16_KERNEL=v1 selects the first of the two bf16 kernel
-                           * designs (A/B runs; same arithmetic) */
+                           * designs (A/B runs; same arithmetic).
+                           * NERF_MLP_BF16X3 (2, opt-in): f32-accurate arithmetic on the bf16 matrix cores -- every weight and
+                           * activation is split into three bf16 parts (exact to 2^-27) and a product is the sum of the six
+                           * significant bf16 x bf16 products, accumulated in f32; meets the f32 path's tolerances */
     int32_t skip_empty;   /* ext: 1 = skip the colour head (bottleneck + viewdirs + rgb, 17 % of a full MLP
                            * evaluation) for every workgroup tile (128 samples in f32, 256 in bf16) whose densities are all 0.
                            * EXACT: such samples have alpha = 0 and weight 0, the image is bit-identical; only the work

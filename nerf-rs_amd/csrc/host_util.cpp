@@ -166,8 +166,9 @@ uint16_t f32_to_bf16_rne(float v) {
 }
 
 // rowfn(tile, r, h): weight row held by register r (0..15) of input tile `tile` on lane-half h, or -1.
+// Emits the layer's 1-KiB pieces (64 lanes x 8 elements) in the order (input tile, k-step, output tile) as f32 values.
 template <class RowFn>
-static void pack_layer_bf16(std::vector<uint16_t> &s, const HostNet::L &L, int n_tiles, int NT, RowFn row) {
+static void pack_layer_v1order(std::vector<float> &s, const HostNet::L &L, int n_tiles, int NT, RowFn row) {
     for (int tt = 0; tt < n_tiles; ++tt)
         for (int ks = 0; ks < 2; ++ks)
             for (int nt = 0; nt < NT; ++nt)
@@ -175,27 +176,66 @@ static void pack_layer_bf16(std::vector<uint16_t> &s, const HostNet::L &L, int n
                     for (int j = 0; j < 8; ++j) { // B-fragment element j of k-step ks = register 8 ks + j of the tile
                         const int r = row(tt, 8 * ks + j, l >> 5);
                         const int n = 32 * nt + (l & 31);
-                        s.push_back((r >= 0 && r < L.K && n < L.N) ? f32_to_bf16_rne(L.w[(size_t)r * L.N + n]) : (uint16_t)0);
+                        s.push_back((r >= 0 && r < L.K && n < L.N) ? L.w[(size_t)r * L.N + n] : 0.0f);
                     }
 }
 
-void pack_network_bf16(const HostNet &net, std::vector<uint16_t> &ws) {
+void pack_network_v1order_f32(const HostNet &net, std::vector<float> &ws) {
     ws.clear();
-    ws.reserve((size_t)kChunksFullBf16 * kChunkBytesBf16 / 2);
+    ws.reserve((size_t)kPiecesV1 * 512);
     auto hid = [](int tt, int r, int h) { return 32 * tt + regFeature(r, h); };
-    pack_layer_bf16(ws, net.dense[0], 2, 8, [](int tt, int r, int h) { return posSlotFeature(16 * tt + r, h); });
-    for (int i = 1; i < 5; ++i) pack_layer_bf16(ws, net.dense[i], 8, 8, hid);
-    pack_layer_bf16(ws, net.dense[5], 10, 8, [](int tt, int r, int h) {
+    pack_layer_v1order(ws, net.dense[0], 2, 8, [](int tt, int r, int h) { return posSlotFeature(16 * tt + r, h); });
+    for (int i = 1; i < 5; ++i) pack_layer_v1order(ws, net.dense[i], 8, 8, hid);
+    pack_layer_v1order(ws, net.dense[5], 10, 8, [](int tt, int r, int h) {
         return tt < 2 ? posSlotFeature(16 * tt + r, h) : 63 + 32 * (tt - 2) + regFeature(r, h);
     });
-    for (int i = 6; i < 8; ++i) pack_layer_bf16(ws, net.dense[i], 8, 8, hid);
-    pack_layer_bf16(ws, net.bottleneck, 8, 8, hid);
-    pack_layer_bf16(ws, net.viewdirs, 9, 4, [](int tt, int r, int h) {
+    for (int i = 6; i < 8; ++i) pack_layer_v1order(ws, net.dense[i], 8, 8, hid);
+    pack_layer_v1order(ws, net.bottleneck, 8, 8, hid);
+    pack_layer_v1order(ws, net.viewdirs, 9, 4, [](int tt, int r, int h) {
         if (tt < 8) return 32 * tt + regFeature(r, h);
         const int f = dirSlotFeature(r, h);
         return f < 0 ? -1 : 256 + f;
     });
+}
+
+void bf16_stream_from_v1order(const std::vector<float> &v1f, std::vector<uint16_t> &ws) {
+    ws.resize(v1f.size());
+    for (size_t i = 0; i < v1f.size(); ++i) ws[i] = f32_to_bf16_rne(v1f[i]);
     ws.resize((size_t)kChunksFullBf16 * kChunkBytesBf16 / 2, (uint16_t)0); // pad viewdirs to whole chunks
+}
+
+void pack_network_bf16(const HostNet &net, std::vector<uint16_t> &ws) {
+    std::vector<float> v1f;
+    pack_network_v1order_f32(net, v1f);
+    bf16_stream_from_v1order(v1f, ws);
+}
+
+static float bf16_to_f32(uint16_t b) {
+    const uint32_t u = (uint32_t)b << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+
+// w = w1 + w2 + w3 (+ at most 2^-27 |w|): w1 = bf16(w), w2 = bf16(w - w1), w3 = bf16(w - w1 - w2); the subtractions are exact.
+void split_bf16x3(float v, uint16_t out[3]) {
+    out[0] = f32_to_bf16_rne(v);
+    const float r1 = v - bf16_to_f32(out[0]);
+    out[1] = f32_to_bf16_rne(r1);
+    const float r2 = r1 - bf16_to_f32(out[1]);
+    out[2] = f32_to_bf16_rne(r2);
+}
+
+// x3 stream: every piece of the v1 order followed by the pieces of the second and third part of the same weights
+void x3_stream_from_v1order(const std::vector<float> &v1f, std::vector<uint16_t> &ws) {
+    const size_t n_pieces = v1f.size() / 512;
+    ws.assign(n_pieces * 3 * 512, (uint16_t)0);
+    for (size_t pc = 0; pc < n_pieces; ++pc)
+        for (int e = 0; e < 512; ++e) {
+            uint16_t parts[3];
+            split_bf16x3(v1f[pc * 512 + e], parts);
+            for (int s3 = 0; s3 < 3; ++s3) ws[(pc * 3 + s3) * 512 + e] = parts[s3];
+        }
 }
 
 // ------------------------------------------------------------------------------------------------

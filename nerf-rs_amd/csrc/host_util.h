@@ -35,6 +35,12 @@ void pack_network(const HostNet &net, std::vector<float> &wstream, std::vector<f
 // bf16 weight stream of mlp_kernel_bf16.hip (round-to-nearest-even); the small-parameter block is shared with fp32.
 void pack_network_bf16(const HostNet &net, std::vector<uint16_t> &wstream);
 uint16_t f32_to_bf16_rne(float v);
+// the first bf16 design's piece order as f32 values, no padding (mlp_layout.h kPiecesV1 x 512): common source of all bf16 streams
+void pack_network_v1order_f32(const HostNet &net, std::vector<float> &v1f);
+void bf16_stream_from_v1order(const std::vector<float> &v1f, std::vector<uint16_t> &wstream);
+// f32 by three-way bf16 split (mlp_kernel_bf16x3.hip): w = w1 + w2 + w3, three pieces per v1 piece
+void split_bf16x3(float v, uint16_t out[3]);
+void x3_stream_from_v1order(const std::vector<float> &v1f, std::vector<uint16_t> &wstream);
 
 // camera_from_samples (src/lib.rs:614-645)
 void camera_from_values(float near_, float far_, const float origin[3], const float forward[3], const float up[3],

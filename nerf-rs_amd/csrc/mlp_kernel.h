@@ -35,3 +35,6 @@ hipError_t nerf_mlp_bf16_launch(const MlpArgs &a, bool full, int n_blocks, hipSt
 // second bf16 design (mlp_kernel_bf16v2.hip): a.wstream is the output-tile-major stream (mlp_layout.h kChunks*Bf16V2)
 hipError_t nerf_mlp_bf16v2_init();
 hipError_t nerf_mlp_bf16v2_launch(const MlpArgs &a, bool full, int n_blocks, hipStream_t stream);
+// f32 by three-way bf16 split (mlp_kernel_bf16x3.hip): a.wstream is the three-part stream (mlp_layout.h kChunks*X3)
+hipError_t nerf_mlp_bf16x3_init();
+hipError_t nerf_mlp_bf16x3_launch(const MlpArgs &a, bool full, int n_blocks, hipStream_t stream);

@@ -1,0 +1,388 @@
+// mlp_kernel_bf16x3.hip -- the fused NeRF MLP in "f32 by three-way bf16 split" arithmetic (mlp_dtype = NERF_MLP_BF16X3).
+//
+// An f32 value is the exact sum of three bf16 numbers up to 2^-27 relative: x = x1 + x2 + x3 with x1 = bf16(x),
+// x2 = bf16(x - x1), x3 = bf16(x - x1 - x2) (every subtraction is exact in f32).  A product w x is then
+//      w1 x1 + (w1 x2 + w2 x1) + (w1 x3 + w2 x2 + w3 x1) + O(2^-26 |w x|)
+// -- six bf16 x bf16 products, each formed EXACTLY by v_mfma_f32_32x32x16_bf16 and accumulated in f32.  The dropped terms are
+// below the f32 rounding of the product itself, so the layer arithmetic is f32-accurate (measured against the f32 oracle in
+// tests/test_gpu_parity.py with the f32 path's own tolerances), while the matrix work runs on the bf16 cores: six 32-cycle
+// MFMAs replace eight 64-cycle f32 MFMAs (2.67 x fewer matrix cycles per f32 FLOP).  Opt-in; the default f32 path
+// (mlp_kernel.hip) stays the reference-order kernel.
+//
+// Structure = the f32 / first bf16 kernel: one persistent 256-thread workgroup per CU, 32 points per wave, activations stay
+// in registers as f32 accumulator tiles (X/Y ping-pong, 128 + 128 registers); k-major loop.  Per k-step (K = 16) the B operand
+// is split on the fly: 8 f32 values per lane -> ReLU -> three packed bf16x8 fragments (about 60 VALU, prepared one k-step
+// ahead, spread behind the MFMAs of the current k-step).  Weights are split on the host.
+// Stream (mlp_layout.h): per layer, input tile, k-step and output tile one UNIT = three 1-KiB pieces (w1, w2, w3 fragments of
+// the same 32 x 16 block); a k-step of an 8-tile layer = 24 pieces = one 24-KiB chunk; 3-slot ring; sync at unit 4 of a chunk;
+// each wave DMA's its six pieces of the chunk after next behind units 4, 5, 6, 7, 0, 1.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <type_traits>
+
+#include "mlp_common.hip.h"
+#include "mlp_kernel.h"
+#include "mlp_layout.h"
+
+using namespace nerfmlp;
+using namespace mlpdev;
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int kCB = kChunkBytesX3, kRS = kRingSlotsX3;
+
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F &&f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+struct PipeX {
+    const LDS_AS char *rd_base;   // LDS address (incl. lane * 16) of the chunk the next prefetched unit lives in
+    const LDS_AS char *ring_lane;
+    uint32_t rd_slot_off;
+    u32x4 a[6];                   // A fragments (w1, w2, w3) of the current unit [parity] and the next one
+    uint32_t ring_addr, wr_slot_off, next_off, stream_bytes;
+    const char *gbase, *cur_src;
+    uint32_t cur_dst, lane16;
+};
+
+__device__ __forceinline__ void pipe_next_chunk(PipeX &P) {
+    uint32_t off = P.next_off, slot = P.wr_slot_off;
+    asm volatile("" : "+s"(off), "+s"(slot));
+    P.cur_src = P.gbase + off;
+    P.cur_dst = P.ring_addr + slot;
+    off += kCB;
+    P.next_off = (off == P.stream_bytes) ? 0u : off;
+    slot += kCB;
+    P.wr_slot_off = (slot == kRS * kCB) ? 0u : slot;
+}
+
+// (Re)start at chunk 0 in the state a steady-state run is in there: chunk 0 landed, chunk 1 selected with the four pieces
+// that units 4..7 of "chunk -1" would have issued (units 0, 1 of chunk 0 issue pieces 4, 5), unit 0 prefetched.  The caller
+// guarantees that no wave still reads the ring.
+__device__ __forceinline__ void pipe_start(PipeX &P) {
+    P.next_off = 0;
+    P.wr_slot_off = 0;
+    pipe_next_chunk(P);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) glds_piece(P.lane16, P.cur_src + i * 1024, P.cur_dst + i * 1024);
+    pipe_next_chunk(P);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) glds_piece(P.lane16, P.cur_src + i * 1024, P.cur_dst + i * 1024);
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    P.rd_slot_off = 0;
+    P.rd_base = P.ring_lane;
+#pragma unroll
+    for (int s = 0; s < 3; ++s) P.a[s] = *(const LDS_AS u32x4 *)(P.rd_base + s * 1024);
+}
+
+// Unit U (0..7 within its chunk) begins: hand out its three A fragments, prefetch the next unit's.  Unit 4: the chunk after
+// this one must have landed (every wave waits for its own pieces, then the barrier) and the slot of the previous chunk may be
+// refilled.
+template <int U>
+__device__ __forceinline__ void pipe_unit(PipeX &P, bf16x8 &a1, bf16x8 &a2, bf16x8 &a3) {
+    if constexpr (U == 4) {
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        pipe_next_chunk(P);
+    }
+    constexpr int cur = (U & 1) * 3, nxt = ((U + 1) & 1) * 3;
+    asm volatile("" : "+v"(P.a[cur]), "+v"(P.a[cur + 1]), "+v"(P.a[cur + 2])); // one s_waitcnt for the three fragments
+    a1 = __builtin_bit_cast(bf16x8, P.a[cur]); a2 = __builtin_bit_cast(bf16x8, P.a[cur + 1]); a3 = __builtin_bit_cast(bf16x8, P.a[cur + 2]);
+    if constexpr (U == 7) {
+        uint32_t off = P.rd_slot_off + kCB;
+        off = (off == kRS * kCB) ? 0u : off;
+        P.rd_slot_off = off;
+        P.rd_base = P.ring_lane + off;
+    }
+    constexpr int nu = (U + 1) & 7;
+#pragma unroll
+    for (int s = 0; s < 3; ++s) P.a[nxt + s] = *(const LDS_AS u32x4 *)(P.rd_base + (3 * nu + s) * 1024);
+}
+
+// the LDS-DMA piece issued behind unit U: pieces of the chunk selected at the last sync, in issue order
+// U 4 -> 0, 5 -> 1, 6 -> 2, 7 -> 3, 0 -> 4, 1 -> 5
+template <int U>
+__device__ __forceinline__ void pipe_dma(PipeX &P) {
+    if constexpr (U >= 4) glds_piece(P.lane16, P.cur_src + (U - 4) * 1024, P.cur_dst + (U - 4) * 1024);
+    else if constexpr (U <= 1) glds_piece(P.lane16, P.cur_src + (U + 4) * 1024, P.cur_dst + (U + 4) * 1024);
+}
+
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
+
+struct B3 { u32x4 h, m, l; }; // the three bf16x8 fragments of one k-step's B operand
+
+// two f32 values -> their three bf16 parts, packed pairwise.  The subtractions are exact: x - bf16(x) has at most 16
+// significant bits left, the next one at most 8.
+template <bool RELU>
+__device__ __forceinline__ void split_pair(float x0, float x1, uint32_t &h, uint32_t &m, uint32_t &l) {
+    if (RELU) { x0 = relu(x0); x1 = relu(x1); }
+    const f32x2 x = {x0, x1};
+    const uint32_t hu = __builtin_bit_cast(uint32_t, __builtin_convertvector(x, bf16x2));
+    const f32x2 hf = {__builtin_bit_cast(float, hu << 16), __builtin_bit_cast(float, hu & 0xffff0000u)};
+    const f32x2 r1 = x - hf;
+    const uint32_t mu = __builtin_bit_cast(uint32_t, __builtin_convertvector(r1, bf16x2));
+    const f32x2 mf = {__builtin_bit_cast(float, mu << 16), __builtin_bit_cast(float, mu & 0xffff0000u)};
+    const f32x2 r2 = r1 - mf;
+    h = hu; m = mu;
+    l = __builtin_bit_cast(uint32_t, __builtin_convertvector(r2, bf16x2));
+}
+
+// pair Q (0..3) of k-step KS (0/1) of an input tile: registers 8 KS + 2 Q, + 1
+template <bool RELU, int KS, int Q>
+__device__ __forceinline__ void prep_pair(const f32x16 &in, B3 &b) {
+    float x0 = in[8 * KS + 2 * Q], x1 = in[8 * KS + 2 * Q + 1];
+    asm volatile("" : "+v"(x0), "+v"(x1)); // keep the accumulator reads here (hipcc otherwise hoists a whole layer's)
+    uint32_t hh, mm, ll;
+    split_pair<RELU>(x0, x1, hh, mm, ll);
+    b.h[Q] = hh; b.m[Q] = mm; b.l[Q] = ll;
+}
+
+template <bool RELU, int KS>
+__device__ __forceinline__ void prep_all(const f32x16 &in, B3 &b) {
+    prep_pair<RELU, KS, 0>(in, b); prep_pair<RELU, KS, 1>(in, b); prep_pair<RELU, KS, 2>(in, b); prep_pair<RELU, KS, 3>(in, b);
+}
+
+// the six products of one unit, small terms first
+__device__ __forceinline__ void unit_mfma(f32x16 &acc, bf16x8 a1, bf16x8 a2, bf16x8 a3, const B3 &b) {
+    const bf16x8 b1 = __builtin_bit_cast(bf16x8, b.h), b2 = __builtin_bit_cast(bf16x8, b.m), b3 = __builtin_bit_cast(bf16x8, b.l);
+    acc = MFMA16(a3, b1, acc);
+    acc = MFMA16(a2, b2, acc);
+    acc = MFMA16(a1, b3, acc);
+    acc = MFMA16(a2, b1, acc);
+    acc = MFMA16(a1, b2, acc);
+    acc = MFMA16(a1, b1, acc);
+}
+
+// One k-step: NT units (units U0 .. U0 + NT - 1 of the chunk) with the prepared B `bc`; behind them, pair by pair, the B
+// operand of the NEXT k-step is split from tile `nin` (its k-step NKS) into `bn` -- nothing if !HAS_NEXT.
+template <int NT, int U0, bool HAS_NEXT, bool NRELU, int NKS>
+__device__ __forceinline__ void k_step(f32x16 (&out)[8], const B3 &bc, const f32x16 &nin, B3 &bn, PipeX &P) {
+    static_for<0, NT>([&](auto nt_c) {
+        constexpr int nt = decltype(nt_c)::value;
+        constexpr int U = U0 + nt;
+        bf16x8 a1, a2, a3;
+        pipe_unit<U>(P, a1, a2, a3);
+        __builtin_amdgcn_sched_barrier(0);
+        unit_mfma(out[nt], a1, a2, a3, bc);
+        __builtin_amdgcn_sched_barrier(0);
+        pipe_dma<U>(P);
+        if constexpr (HAS_NEXT) { // pair q behind unit 2 q (8-tile layers) or unit min(q, 2) (viewdirs): done before the last unit
+            if constexpr (NT == 8) {
+                if constexpr (nt == 0) prep_pair<NRELU, NKS, 0>(nin, bn);
+                if constexpr (nt == 2) prep_pair<NRELU, NKS, 1>(nin, bn);
+                if constexpr (nt == 4) prep_pair<NRELU, NKS, 2>(nin, bn);
+                if constexpr (nt == 6) prep_pair<NRELU, NKS, 3>(nin, bn);
+            } else {
+                if constexpr (nt == 0) prep_pair<NRELU, NKS, 0>(nin, bn);
+                if constexpr (nt == 1) prep_pair<NRELU, NKS, 1>(nin, bn);
+                if constexpr (nt == 2) { prep_pair<NRELU, NKS, 2>(nin, bn); prep_pair<NRELU, NKS, 3>(nin, bn); }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    });
+}
+
+// One input tile (two k-steps) of a layer with NT output tiles.  `b` holds the split B of this tile's k-step 0 on entry and
+// of the next tile's k-step 0 on exit (if HAS_NEXT).  Every tile starts on a chunk boundary: a k-step is 8 units = one chunk in
+// the 8-tile layers and 4 units in the 4-tile viewdirs layer, where the tile's second k-step therefore starts at unit 4.
+template <int NT, bool RELU, bool ACC_IN, bool HAS_NEXT, bool NRELU, bool NACC_IN>
+__device__ __forceinline__ void tile_steps(f32x16 &in, f32x16 &nin, f32x16 (&out)[8], B3 &b, PipeX &P) {
+    if constexpr (ACC_IN) asm volatile("" : "+a"(in));
+    B3 b1;
+    k_step<NT, 0, true, RELU, 1>(out, b, in, b1, P);
+    if constexpr (HAS_NEXT && NACC_IN) asm volatile("" : "+a"(nin));
+    k_step<NT, (NT == 8 ? 0 : 4), HAS_NEXT, NRELU, 0>(out, b1, nin, b, P);
+    // keep every accumulation chain in program order (see mlp_kernel_bf16.hip)
+    if constexpr (NT == 8)
+        asm volatile("" : "+a"(out[0]), "+a"(out[1]), "+a"(out[2]), "+a"(out[3]), "+a"(out[4]), "+a"(out[5]), "+a"(out[6]), "+a"(out[7]));
+    else
+        asm volatile("" : "+a"(out[0]), "+a"(out[1]), "+a"(out[2]), "+a"(out[3]));
+}
+
+template <int NT>
+__device__ __forceinline__ void load_bias(f32x16 (&out)[8], const LDS_AS float *bias, int h) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const LDS_AS f32x4 *b = (const LDS_AS f32x4 *)(bias + (nt * 2 + h) * 16);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 v = b[q];
+            out[nt][4 * q + 0] = v[0]; out[nt][4 * q + 1] = v[1]; out[nt][4 * q + 2] = v[2]; out[nt][4 * q + 3] = v[3];
+        }
+    }
+}
+
+// the 8 input tiles of a 256-wide activation; `b` = split B of in[0]'s k-step 0 on entry
+template <int NT, bool RELU>
+__device__ __forceinline__ void eight_tiles(f32x16 (&in)[8], f32x16 (&out)[8], B3 &b, PipeX &P) {
+    tile_steps<NT, RELU, true, true, RELU, true>(in[0], in[1], out, b, P);
+    tile_steps<NT, RELU, true, true, RELU, true>(in[1], in[2], out, b, P);
+    tile_steps<NT, RELU, true, true, RELU, true>(in[2], in[3], out, b, P);
+    tile_steps<NT, RELU, true, true, RELU, true>(in[3], in[4], out, b, P);
+    tile_steps<NT, RELU, true, true, RELU, true>(in[4], in[5], out, b, P);
+    tile_steps<NT, RELU, true, true, RELU, true>(in[5], in[6], out, b, P);
+    tile_steps<NT, RELU, true, true, RELU, true>(in[6], in[7], out, b, P);
+}
+
+template <bool RELU>
+__device__ __forceinline__ void hidden_layer(f32x16 (&in)[8], f32x16 (&out)[8], const LDS_AS float *bias, PipeX &P, int h) {
+    load_bias<8>(out, bias, h);
+    B3 b;
+    asm volatile("" : "+a"(in[0]));
+    prep_all<RELU, 0>(in[0], b);
+    eight_tiles<8, RELU>(in, out, b, P);
+    tile_steps<8, RELU, true, false, false, false>(in[7], in[7], out, b, P);
+}
+
+__device__ __forceinline__ float alpha_head(const f32x16 (&Y)[8], const LDS_AS float *small, int h) {
+    const LDS_AS f32x4 *w = (const LDS_AS f32x4 *)(small + kAlphaWOff + h * 128);
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float x0 = Y[t][4 * q + 0], x1 = Y[t][4 * q + 1], x2 = Y[t][4 * q + 2], x3 = Y[t][4 * q + 3];
+            asm volatile("" : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3));
+            const f32x4 wv = w[t * 4 + q];
+            a0 = fmaf(wv[0], relu(x0), a0);
+            a1 = fmaf(wv[1], relu(x1), a1);
+            a2 = fmaf(wv[2], relu(x2), a2);
+            a3 = fmaf(wv[3], relu(x3), a3);
+        }
+    }
+    return fmaxf(xhalf_sum((a0 + a1) + (a2 + a3)) + small[kMiscOff + 0], 0.f);
+}
+
+} // namespace
+
+template <bool FULL, int MODE>
+__global__ __launch_bounds__(256, 1) void nerf_mlp_kernel_bf16x3(const MlpArgs A) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const LDS_AS char *lds = (const LDS_AS char *)smem;
+    const LDS_AS float *small = (const LDS_AS float *)(lds + kRS * kCB);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int p = lane & 31;
+    const int h = lane >> 5;
+
+    {
+        float *dst = (float *)(smem + kRS * kCB);
+        for (int i = tid; i < kSmallFloats; i += 256) dst[i] = A.small_params[i];
+    }
+    PipeX P;
+    P.lane16 = lane * 16;
+    P.ring_lane = lds + P.lane16;
+    P.ring_addr = (uint32_t)(uintptr_t)lds + wave * 6144; // this wave's six pieces of a chunk
+    P.stream_bytes = (FULL ? kChunksFullX3 : kChunksSigmaX3) * kCB;
+    P.gbase = (const char *)A.wstream + wave * 6144;
+    __syncthreads();
+    pipe_start(P);
+
+    const int n_tiles = (A.n_points + kPointsPerBlock - 1) / kPointsPerBlock;
+    RawIn nxt = load_raw<MODE>(A, blockIdx.x, wave, p);
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int i = tile * kPointsPerBlock + wave * kPointsPerWave + p;
+        const bool valid = i < A.n_points;
+        const RawIn in = nxt;
+        nxt = load_raw<MODE>(A, tile + gridDim.x, wave, p);
+        float px, py, pz;
+        point_of<MODE>(A, in, px, py, pz);
+        const float dx = in.dx, dy = in.dy, dz = in.dz;
+
+        f32x16 E[2];
+        encode_point<true>(px, py, pz, h, E);
+
+        f32x16 X[8], Y[8];
+        B3 b;
+        load_bias<8>(X, small + kBiasOff + 0 * 256, h);          // dense0 (src/network.rs:204)
+        prep_all<false, 0>(E[0], b);
+        tile_steps<8, false, false, true, false, false>(E[0], E[1], X, b, P);
+        tile_steps<8, false, false, false, false, false>(E[1], E[1], X, b, P);
+        hidden_layer<true>(X, Y, small + kBiasOff + 1 * 256, P, h);
+        hidden_layer<true>(Y, X, small + kBiasOff + 2 * 256, P, h);
+        hidden_layer<true>(X, Y, small + kBiasOff + 3 * 256, P, h);
+        hidden_layer<true>(Y, X, small + kBiasOff + 4 * 256, P, h);
+        load_bias<8>(Y, small + kBiasOff + 5 * 256, h);          // dense5 on [encoding ; h4] (:209-210)
+        prep_all<false, 0>(E[0], b);
+        tile_steps<8, false, false, true, false, false>(E[0], E[1], Y, b, P);
+        tile_steps<8, false, false, true, true, true>(E[1], X[0], Y, b, P);
+        eight_tiles<8, true>(X, Y, b, P);
+        tile_steps<8, true, true, false, false, false>(X[7], X[7], Y, b, P);
+        hidden_layer<true>(Y, X, small + kBiasOff + 6 * 256, P, h);
+        hidden_layer<true>(X, Y, small + kBiasOff + 7 * 256, P, h);
+
+        const float sigma = alpha_head(Y, small, h);
+        if (valid && h == 0) A.sigma_out[i] = sigma;
+
+        if (FULL && A.skip_empty) { // exact empty-tile skip, see mlp_kernel.hip
+            LDS_AS int *vote = (LDS_AS int *)(lds + kRS * kCB) + kMiscOff + 8;
+            const bool any_wg = tile_has_density(vote, valid && sigma > 0.0f, wave, lane);
+            if (!any_wg) {
+                if (valid && h == 0) {
+                    A.rgb_out[3 * (size_t)i + 0] = 0.f; A.rgb_out[3 * (size_t)i + 1] = 0.f; A.rgb_out[3 * (size_t)i + 2] = 0.f;
+                }
+                if (A.skip_counter && tid == 0) atomicAdd(A.skip_counter, 1ull);
+                asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory"); // in-flight chunks landed; ring idle
+                pipe_start(P);
+                continue;
+            }
+        }
+
+        if (FULL) {
+            hidden_layer<true>(Y, X, small + kBiasOff + 8 * 256, P, h); // bottleneck: no activation on its output (:218)
+            f32x16 D;
+            encode_dir<true>(dx, dy, dz, h, D);
+            f32x16 (&V)[8] = Y;                                          // Y is dead after the bottleneck
+            load_bias<4>(V, small + kBiasViewOff, h);
+            asm volatile("" : "+a"(X[0]));
+            prep_all<false, 0>(X[0], b);
+            eight_tiles<4, false>(X, V, b, P);
+            tile_steps<4, false, true, true, false, false>(X[7], D, V, b, P);
+            tile_steps<4, false, false, false, false, false>(D, D, V, b, P);
+            float c[3];
+            rgb_head(V, small, h, c);
+            if (valid && h == 0) {
+                A.rgb_out[3 * (size_t)i + 0] = c[0];
+                A.rgb_out[3 * (size_t)i + 1] = c[1];
+                A.rgb_out[3 * (size_t)i + 2] = c[2];
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+template <bool FULL, int MODE>
+static hipError_t launch_t(const MlpArgs &a, int n_blocks, hipStream_t stream) {
+    hipLaunchKernelGGL((nerf_mlp_kernel_bf16x3<FULL, MODE>), dim3(n_blocks), dim3(256), kLdsBytesX3, stream, a);
+    return hipGetLastError();
+}
+
+hipError_t nerf_mlp_bf16x3_init() {
+    const void *ks[4] = {(const void *)nerf_mlp_kernel_bf16x3<true, MLP_MODE_POINTS>, (const void *)nerf_mlp_kernel_bf16x3<false, MLP_MODE_POINTS>,
+                         (const void *)nerf_mlp_kernel_bf16x3<true, MLP_MODE_RAYS>, (const void *)nerf_mlp_kernel_bf16x3<false, MLP_MODE_RAYS>};
+    for (int i = 0; i < 4; ++i) {
+        hipError_t e = hipFuncSetAttribute(ks[i], hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytesX3);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
+hipError_t nerf_mlp_bf16x3_launch(const MlpArgs &a, bool full, int n_blocks, hipStream_t stream) {
+    if (a.n_points <= 0) return hipSuccess;
+    const int n_tiles = (a.n_points + kPointsPerBlock - 1) / kPointsPerBlock;
+    if (n_blocks > n_tiles) n_blocks = n_tiles;
+    if (n_blocks < 1) n_blocks = 1;
+    if (a.mode == MLP_MODE_POINTS)
+        return full ? launch_t<true, MLP_MODE_POINTS>(a, n_blocks, stream) : launch_t<false, MLP_MODE_POINTS>(a, n_blocks, stream);
+    return full ? launch_t<true, MLP_MODE_RAYS>(a, n_blocks, stream) : launch_t<false, MLP_MODE_RAYS>(a, n_blocks, stream);
+}

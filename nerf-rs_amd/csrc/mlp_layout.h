@@ -73,6 +73,16 @@ constexpr int kChunksFullBf16V2 = kChunksSigmaBf16V2 + (128 + 72 + 8) / 16; // 7
 constexpr int kLdsBytesBf16V2 = kRingSlotsBf16V2 * kChunkBytesBf16V2 + kSmallBytes;
 constexpr int kPointsPerBlockBf16V2 = 256;
 
+// ---- bf16x3 stream (mlp_kernel_bf16x3.hip, f32 by three-way bf16 split): the first bf16 design's pieces in the same order
+// (layer, input tile, k-step, output tile), each followed by the pieces of the second and third bf16 part of the same
+// weights: a unit = 3 KiB, a k-step of an 8-tile layer = 24 KiB = one chunk, a k-step of viewdirs half a chunk.  No padding.
+constexpr int kChunkBytesX3 = 24576;
+constexpr int kRingSlotsX3 = 3;
+constexpr int kChunksSigmaX3 = 2 * 2 + 4 * 16 + 20 + 2 * 16;  // dense0 (2 tiles x 2 k-steps), dense1-4, dense5, dense6-7 = 120
+constexpr int kChunksFullX3 = kChunksSigmaX3 + 16 + 9;        // + bottleneck + viewdirs (9 tiles, one chunk each) = 145
+constexpr int kLdsBytesX3 = kRingSlotsX3 * kChunkBytesX3 + kSmallBytes;
+constexpr int kPiecesV1 = 8 * (4 + 4 * 16 + 20 + 3 * 16) + 4 * 18;  // 1160 pieces of the first bf16 design, without its padding
+
 // feature held by register r (0..15) of a tile on lane-half h, relative to the tile's first feature
 constexpr int regFeature(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 

@@ -31,6 +31,7 @@ struct DevNet {
     float *wstream = nullptr, *small = nullptr;
     uint16_t *wstream_bf16 = nullptr; // built from the same tensors at load time (mlp_kernel_bf16.hip)
     uint16_t *wstream_bf16v2 = nullptr; // the same pieces in output-tile-major order (mlp_kernel_bf16v2.hip)
+    uint16_t *wstream_x3 = nullptr;     // three bf16 parts per weight (mlp_kernel_bf16x3.hip)
     bool loaded = false;
 };
 
@@ -142,11 +143,14 @@ int ensure_workspace(nerf_ctx *c, size_t rays, size_t nc, size_t m) {
 int upload_packed(nerf_ctx *c, int which, const std::vector<float> &ws, const std::vector<float> &sm);
 
 // weight stream + launcher of the selected arithmetic
-static const float *stream_of(const nerf_ctx *c, const DevNet &n, bool bf16) {
-    return !bf16 ? n.wstream : (const float *)(c->bf16_v1 ? n.wstream_bf16 : n.wstream_bf16v2);
+static bool valid_dtype(int d) { return d == NERF_MLP_F32 || d == NERF_MLP_BF16 || d == NERF_MLP_BF16X3; }
+static const float *stream_of(const nerf_ctx *c, const DevNet &n, int dtype) {
+    if (dtype == NERF_MLP_BF16X3) return (const float *)n.wstream_x3;
+    return dtype == NERF_MLP_F32 ? n.wstream : (const float *)(c->bf16_v1 ? n.wstream_bf16 : n.wstream_bf16v2);
 }
-static hipError_t launch_mlp(const nerf_ctx *c, bool bf16, const MlpArgs &a, bool full, hipStream_t st) {
-    if (!bf16) return nerf_mlp_launch(a, full, c->n_cus, st);
+static hipError_t launch_mlp(const nerf_ctx *c, int dtype, const MlpArgs &a, bool full, hipStream_t st) {
+    if (dtype == NERF_MLP_F32) return nerf_mlp_launch(a, full, c->n_cus, st);
+    if (dtype == NERF_MLP_BF16X3) return nerf_mlp_bf16x3_launch(a, full, c->n_cus, st);
     return c->bf16_v1 ? nerf_mlp_bf16_launch(a, full, c->n_cus, st) : nerf_mlp_bf16v2_launch(a, full, c->n_cus, st);
 }
 
@@ -173,14 +177,21 @@ static void bf16_v2_from_v1(const std::vector<uint16_t> &v1, std::vector<uint16_
     v2.resize((size_t)kChunksFullBf16V2 * kChunkBytesBf16V2 / 2, (uint16_t)0);
 }
 
-int upload_bf16(nerf_ctx *c, int which, const std::vector<uint16_t> &wb) {
+// All bf16-family streams come from one f32 array in the first bf16 design's piece order (host_util.h).
+int upload_bf16_family(nerf_ctx *c, int which, const std::vector<float> &v1f) {
+    if (v1f.size() != (size_t)nerfmlp::kPiecesV1 * 512) return fail(c, NERF_ERR_SHAPE, "internal: bf16 piece array has the wrong size");
     DevNet &d = c->net[which];
+    std::vector<uint16_t> wb, v2, x3;
+    bf16_stream_from_v1order(v1f, wb);
+    bf16_v2_from_v1(wb, v2);
+    x3_stream_from_v1order(v1f, x3);
+    if (x3.size() != (size_t)nerfmlp::kChunksFullX3 * nerfmlp::kChunkBytesX3 / 2) return fail(c, NERF_ERR_SHAPE, "internal: bf16x3 stream size");
     if (!d.wstream_bf16) HIP_TRY(c, hipMalloc((void **)&d.wstream_bf16, wb.size() * sizeof(uint16_t)));
     HIP_TRY(c, hipMemcpy(d.wstream_bf16, wb.data(), wb.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
-    std::vector<uint16_t> v2;
-    bf16_v2_from_v1(wb, v2);
     if (!d.wstream_bf16v2) HIP_TRY(c, hipMalloc((void **)&d.wstream_bf16v2, v2.size() * sizeof(uint16_t)));
     HIP_TRY(c, hipMemcpy(d.wstream_bf16v2, v2.data(), v2.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    if (!d.wstream_x3) HIP_TRY(c, hipMalloc((void **)&d.wstream_x3, x3.size() * sizeof(uint16_t)));
+    HIP_TRY(c, hipMemcpy(d.wstream_x3, x3.data(), x3.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
     return NERF_OK;
 }
 
@@ -189,17 +200,17 @@ int upload_net(nerf_ctx *c, int which, const HostNet &hn) {
     pack_network(hn, ws, sm);
     int rc = upload_packed(c, which, ws, sm);
     if (rc) return rc;
-    std::vector<uint16_t> wb;
-    pack_network_bf16(hn, wb);
-    return upload_bf16(c, which, wb);
+    std::vector<float> v1f;
+    pack_network_v1order_f32(hn, v1f);
+    return upload_bf16_family(c, which, v1f);
 }
 
-// The bf16 stream holds the same weights in another order; for networks that arrive as a packed f32 blob it is
+// The bf16-family streams hold the same weights in another order; for networks that arrive as a packed f32 blob they are
 // rebuilt from the f32 stream's pieces (piece (s, g): lane l, q -> W[row(s, l >> 5)][32 (4 g + q) + (l & 31)]).
 int bf16_from_f32_stream(nerf_ctx *c, int which, const std::vector<float> &ws) {
     using namespace nerfmlp;
-    std::vector<uint16_t> wb;
-    wb.reserve((size_t)kChunksFullBf16 * kChunkBytesBf16 / 2);
+    std::vector<float> v1f;
+    v1f.reserve((size_t)kPiecesV1 * 512);
     size_t layer_base = 0; // floats
     auto layer = [&](int n_tiles, int NT) {
         for (int tt = 0; tt < n_tiles; ++tt)
@@ -209,7 +220,7 @@ int bf16_from_f32_stream(nerf_ctx *c, int which, const std::vector<float> &ws) {
                         for (int j = 0; j < 8; ++j) {
                             const int st = 16 * tt + 8 * ks + j; // f32 k-step that holds register 8 ks + j of tile tt
                             const size_t piece = layer_base + ((size_t)st * (NT / 4) + nt / 4) * 256;
-                            wb.push_back(f32_to_bf16_rne(ws[piece + (size_t)l * 4 + (nt & 3)]));
+                            v1f.push_back(ws[piece + (size_t)l * 4 + (nt & 3)]);
                         }
         layer_base += (size_t)n_tiles * 16 * NT * 64;
     };
@@ -218,8 +229,7 @@ int bf16_from_f32_stream(nerf_ctx *c, int which, const std::vector<float> &ws) {
     layer(10, 8);
     for (int i = 0; i < 3; ++i) layer(8, 8);
     layer(9, 4);
-    wb.resize((size_t)kChunksFullBf16 * kChunkBytesBf16 / 2, (uint16_t)0);
-    return upload_bf16(c, which, wb);
+    return upload_bf16_family(c, which, v1f);
 }
 
 int upload_packed(nerf_ctx *c, int which, const std::vector<float> &ws, const std::vector<float> &sm) {
@@ -277,8 +287,9 @@ int render_device(nerf_ctx *c, const nerf_camera *cam, const nerf_render_opts *o
     if (o->n_coarse <= 0) return fail(c, NERF_ERR_INVALID, "coarse samples per ray must be greater than 0"); // src/lib.rs:483-486
     if (o->n_fine < 0) return fail(c, NERF_ERR_INVALID, "fine samples per ray must be >= 0");
     for (int r : o->reserved) if (r != 0) return fail(c, NERF_ERR_INVALID, "reserved option fields must be 0");
-    if (o->mlp_dtype != NERF_MLP_F32 && o->mlp_dtype != NERF_MLP_BF16) return fail(c, NERF_ERR_INVALID, "mlp_dtype must be NERF_MLP_F32 or NERF_MLP_BF16");
-    const bool bf16 = o->mlp_dtype == NERF_MLP_BF16;
+    if (!valid_dtype(o->mlp_dtype)) return fail(c, NERF_ERR_INVALID, "mlp_dtype must be NERF_MLP_F32, NERF_MLP_BF16 or NERF_MLP_BF16X3");
+    const int dtype = o->mlp_dtype;
+    const bool bf16 = dtype == NERF_MLP_BF16;
     if (o->skip_empty != 0 && o->skip_empty != 1) return fail(c, NERF_ERR_INVALID, "skip_empty must be 0 or 1");
     if (!c->net[NERF_NET_COARSE].loaded) return fail(c, NERF_ERR_STATE, "coarse network not loaded");
     if (!o->coarse_only && !c->net[NERF_NET_FINE].loaded) return fail(c, NERF_ERR_STATE, "fine network not loaded");
@@ -327,13 +338,13 @@ int render_device(nerf_ctx *c, const nerf_camera *cam, const nerf_render_opts *o
         a.ray_dirs = c->d_dirs;
         a.origin[0] = cam->pos[0]; a.origin[1] = cam->pos[1]; a.origin[2] = cam->pos[2];
         // coarse network: sigma only unless its colours are composited (reference discards them, src/lib.rs:404)
-        a.wstream = stream_of(c, NC, bf16); a.small_params = NC.small;
+        a.wstream = stream_of(c, NC, dtype); a.small_params = NC.small;
         a.n_points = n_rays * nc; a.samples_per_ray = nc; a.t = c->d_tc;
         a.sigma_out = c->d_sc; a.rgb_out = c->d_rgbc;
         a.skip_empty = o->skip_empty; a.skip_counter = o->skip_empty ? c->d_skip : nullptr; // only full kernels look at it
         {
             Timed t(c, st, o->coarse_only ? 1 : 0, (uint64_t)a.n_points, timing);
-            HIP_TRY(c, launch_mlp(c, bf16, a, o->coarse_only != 0, st));
+            HIP_TRY(c, launch_mlp(c, dtype, a, o->coarse_only != 0, st));
             t.done(c->last_render);
         }
         float *pass_out = ray_out + (size_t)row * RW * 3;
@@ -357,14 +368,14 @@ int render_device(nerf_ctx *c, const nerf_camera *cam, const nerf_render_opts *o
             t.done(c->last_render);
             t_fine = c->d_tf;
         }
-        a.wstream = stream_of(c, NF, bf16); a.small_params = NF.small;
+        a.wstream = stream_of(c, NF, dtype); a.small_params = NF.small;
         a.n_points = n_rays * M; a.samples_per_ray = M; a.t = t_fine;
         a.sigma_out = c->d_sf; a.rgb_out = c->d_rgbf;
         a.clock_out = c->d_clock; // NULL unless NERF_DEBUG_CLOCK=1
-        c->clock_valid = c->d_clock != nullptr && !(bf16 && c->bf16_v1); // the first bf16 design does not write the stamps
+        c->clock_valid = c->d_clock != nullptr && !(bf16 && c->bf16_v1) && dtype != NERF_MLP_BF16X3; // those kernels write no stamps
         {
             Timed t(c, st, 1, (uint64_t)a.n_points, timing);
-            HIP_TRY(c, launch_mlp(c, bf16, a, true, st));
+            HIP_TRY(c, launch_mlp(c, dtype, a, true, st));
             t.done(c->last_render);
         }
         ca.n = M; ca.t = t_fine; ca.sigma = c->d_sf; ca.rgb = c->d_rgbf;
@@ -452,6 +463,7 @@ int nerf_create(int device_id, nerf_ctx **out) {
     hipError_t e1 = nerf_mlp_init();
     if (e1 == hipSuccess) e1 = nerf_mlp_bf16_init();
     if (e1 == hipSuccess) e1 = nerf_mlp_bf16v2_init();
+    if (e1 == hipSuccess) e1 = nerf_mlp_bf16x3_init();
     hipError_t e2 = e1 == hipSuccess ? sampling_init() : e1;
     hipError_t e3 = e2 == hipSuccess ? hipStreamCreate(&c->stream) : e2;
     if (e3 != hipSuccess) {
@@ -467,7 +479,7 @@ void nerf_destroy(nerf_ctx *c) {
     if (!c) return;
     DeviceGuard dg(c->device);
     (void)hipDeviceSynchronize();
-    for (auto &n : c->net) { if (n.wstream) (void)hipFree(n.wstream); if (n.small) (void)hipFree(n.small); if (n.wstream_bf16) (void)hipFree(n.wstream_bf16); if (n.wstream_bf16v2) (void)hipFree(n.wstream_bf16v2); }
+    for (auto &n : c->net) { if (n.wstream) (void)hipFree(n.wstream); if (n.small) (void)hipFree(n.small); if (n.wstream_bf16) (void)hipFree(n.wstream_bf16); if (n.wstream_bf16v2) (void)hipFree(n.wstream_bf16v2); if (n.wstream_x3) (void)hipFree(n.wstream_x3); }
     float *ptrs[] = {c->d_dirs, c->d_tc, c->d_sc, c->d_rgbc, c->d_tf, c->d_sf, c->d_rgbf, c->d_rayfb, c->d_out};
     for (float *p : ptrs) if (p) (void)hipFree(p);
     if (c->d_scratch) (void)hipFree(c->d_scratch);
@@ -626,11 +638,10 @@ static int forward_device(nerf_ctx *c, int which, int dtype, const float *d_pts,
     DeviceGuard dg(c->device);
     MlpArgs a{};
     a.mode = MLP_MODE_POINTS;
-    if (dtype != NERF_MLP_F32 && dtype != NERF_MLP_BF16) return fail(c, NERF_ERR_INVALID, "mlp_dtype must be NERF_MLP_F32 or NERF_MLP_BF16");
-    const bool bf16 = dtype == NERF_MLP_BF16;
-    a.wstream = stream_of(c, c->net[which], bf16); a.small_params = c->net[which].small;
+    if (!valid_dtype(dtype)) return fail(c, NERF_ERR_INVALID, "mlp_dtype must be NERF_MLP_F32, NERF_MLP_BF16 or NERF_MLP_BF16X3");
+    a.wstream = stream_of(c, c->net[which], dtype); a.small_params = c->net[which].small;
     a.n_points = (int)n; a.pts_soa = d_pts; a.dirs_aos = d_dirs; a.sigma_out = d_sigma; a.rgb_out = d_rgb;
-    HIP_TRY(c, launch_mlp(c, bf16, a, true, (hipStream_t)stream));
+    HIP_TRY(c, launch_mlp(c, dtype, a, true, (hipStream_t)stream));
     return NERF_OK;
 }
 

@@ -16,7 +16,7 @@
 static void usage(const char *argv0) {
     fprintf(stderr,
             "usage: %s [--scene DIR] [--width W] [--height H] [--coarse N] [--fine N] [--seed S] [--ssaa S]\n"
-            "          [--coarse-only] [--crop X0,Y0,W,H] [--dtype f32|bf16] [--device ID] [--frames K] [--out FILE.ppm]\n"
+            "          [--coarse-only] [--crop X0,Y0,W,H] [--dtype f32|bf16|bf16x3] [--device ID] [--frames K] [--out FILE.ppm]\n"
             "defaults: --scene lego_rust --width 256 --height 256 --coarse 64 --fine 128 --out output.ppm\n",
             argv0);
 }
@@ -39,7 +39,7 @@ int main(int argc, char **argv) {
         else if (a == "--seed") opts.seed = strtoull(next(), nullptr, 10);
         else if (a == "--ssaa") opts.ssaa = atoi(next());
         else if (a == "--coarse-only") opts.coarse_only = 1;
-        else if (a == "--dtype") { const std::string d = next(); if (d == "bf16") opts.mlp_dtype = NERF_MLP_BF16; else if (d != "f32") { usage(argv[0]); return 2; } }
+        else if (a == "--dtype") { const std::string d = next(); if (d == "bf16") opts.mlp_dtype = NERF_MLP_BF16; else if (d == "bf16x3") opts.mlp_dtype = NERF_MLP_BF16X3; else if (d != "f32") { usage(argv[0]); return 2; } }
         else if (a == "--device") device = atoi(next());
         else if (a == "--frames") frames = atoi(next());
         else if (a == "--out") out = next();
@@ -78,11 +78,12 @@ int main(int argc, char **argv) {
     nerf_device_info(ctx, &n_cus, arch, sizeof arch);
     const double flop_ray = opts.coarse_only ? opts.n_coarse * 1186816.0
                                              : opts.n_coarse * 982528.0 + (double)(opts.n_coarse + opts.n_fine) * 1186816.0;
-    const bool bf16 = opts.mlp_dtype == NERF_MLP_BF16;
+    const bool bf16 = opts.mlp_dtype != NERF_MLP_F32;
+    const double mfma_flops = opts.mlp_dtype == NERF_MLP_BF16X3 ? 6.0 : 1.0; // executed bf16 MFMA flops per algorithmic f32 flop
     printf("device %s (%d CUs): %.0f rays/s (best of %d, host wall incl. D2H); device %.1f ms = coarse MLP %.1f + fine MLP %.1f + other %.1f; "
            "%.1f%% of the %s MFMA roofline\n",
            arch, n_cus, (double)st.n_rays / best, frames, st.ms_total, st.ms_coarse_mlp, st.ms_fine_mlp, st.ms_other,
-           100.0 * (double)st.n_rays * flop_ray / (st.ms_total * 1e-3) / (bf16 ? 2500e12 : 157.3e12),
+           100.0 * mfma_flops * (double)st.n_rays * flop_ray / (st.ms_total * 1e-3) / (bf16 ? 2500e12 : 157.3e12),
            bf16 ? "2.5 PFLOP/s bf16" : "157.3 TFLOP/s fp32");
     if (nerf_save_ppm(out.c_str(), ow, oh, image.data())) { fprintf(stderr, "error: %s\n", nerf_last_error(nullptr)); return 1; } // :676
     nerf_destroy(ctx);

@@ -509,6 +509,55 @@ def test_skip_empty_is_bit_exact(renderer, native, samples):
     assert np.array_equal(b_img, b_ref) and b_st.n_colour_skipped_points > 0.2 * b_st.n_fine_points
 
 
+# ---- bf16x3: f32 by three-way bf16 split (opt-in arithmetic), held to the f32 path's own tolerances -----------------------
+def test_bf16x3_forward_meets_f32_tolerances(renderer, samples, oracle_nets):
+    """mlp_kernel_bf16x3.hip computes every f32 product as the six significant bf16 x bf16 products of three-way splits.  It must
+    pass the SAME checks as the f32 kernel: the reference's 120 golden scalars, the 4096-point fixture, 65536 live-oracle
+    points, ragged sizes; and its error against the oracle must stay at the f32 kernel's level."""
+    origin = np.float32(samples["camera_origin"]); z = np.float32(samples["z_vals"])
+    for ex in samples["examples"]:
+        rd = np.float32(ex["ray_d"])
+        pts = (origin[:, None] + rd[:, None] * z[None, :]).astype(np.float32)
+        dirs = np.tile(np.float32(ex["viewdir_unit"]), (5, 1))
+        for net, ks, kr in ((renderer.coarse, "coarse_sigma", "coarse_rgb"), (renderer.fine, "fine_sigma", "fine_rgb")):
+            rgb, sg = net.forward_batch(pts, dirs, dtype="bf16x3")
+            _close_mlp(rgb, sg, np.float32(ex[kr]), np.float32(ex[ks]))
+    g = golden("forward_batch_4096.npz")
+    for name, net in (("coarse", renderer.coarse), ("fine", renderer.fine)):
+        rgb, sg = net.forward_batch(g["pts"], g["dirs"], dtype="bf16x3")
+        _close_mlp(rgb, sg, g[f"{name}_rgb"], g[f"{name}_sigma"])
+        f_rgb, f_sg = net.forward_batch(g["pts"], g["dirs"])
+        ex3 = np.abs(sg - g[f"{name}_sigma"]) / (1 + np.abs(g[f"{name}_sigma"]))
+        ef = np.abs(f_sg - g[f"{name}_sigma"]) / (1 + np.abs(g[f"{name}_sigma"]))
+        print(f"\n{name}: sigma rel err vs oracle  bf16x3 max {ex3.max():.2e} mean {ex3.mean():.2e} | f32 kernel max {ef.max():.2e} mean {ef.mean():.2e}"
+              f" | rgb bf16x3 max {np.abs(rgb - g[name + '_rgb']).max():.2e} f32 max {np.abs(f_rgb - g[name + '_rgb']).max():.2e}")
+        assert ex3.max() <= 3 * max(ef.max(), 1e-6) + 1e-6      # same error level as the f32 MFMA kernel
+    for n in (1, 33, 129, 1000):
+        r2, s2 = renderer.fine.forward_batch(g["pts"][:, :n], g["dirs"][:n], dtype="bf16x3")
+        assert np.array_equal(s2, sg[:n]) and np.array_equal(r2, rgb[:n])
+    rng = np.random.default_rng(42)
+    n = 65536
+    pts = rng.uniform(-2.2, 2.2, size=(3, n)).astype(np.float32)
+    v = rng.normal(size=(n, 3)); dirs = (v / np.linalg.norm(v, axis=1, keepdims=True)).astype(np.float32)
+    for net, onet in ((renderer.coarse, oracle_nets[0]), (renderer.fine, oracle_nets[1])):
+        rgb, sg = net.forward_batch(pts, dirs, dtype="bf16x3")
+        ergb, esg = onet.forward_batch(pts, dirs)
+        _close_mlp(rgb, sg, ergb, esg)
+
+
+def test_bf16x3_render_matches_oracle_crop(renderer, native, samples):
+    """The C3 crop (800x800, 64 + 128) through the bf16x3 arithmetic: the f32 path's frame tolerance, and skip_empty exact."""
+    cam = native.camera_from_samples(samples, 800, 800, 64)
+    a = golden("crop_c3_800_64_128.npz")
+    crop = tuple(int(v) for v in a["crop"])
+    img = native.render_image(renderer.coarse, renderer.fine, cam, 128, seed=0, crop=crop, dtype="bf16x3")
+    d = np.abs(img - a["image"])
+    print(f"\nbf16x3 crop vs oracle: max {d.max():.2e} mean {d.mean():.2e} psnr {psnr(img, a['image']):.1f} dB")
+    assert np.quantile(d, 0.999) <= 2e-5 and d.max() <= 2e-3 and psnr(img, a["image"]) >= 80.0
+    sk = native.render_image(renderer.coarse, renderer.fine, cam, 128, seed=0, crop=crop, dtype="bf16x3", skip_empty=True)
+    assert np.array_equal(sk, img)
+
+
 def _forward_fp64(scene_sub, pts, dirs):
     """The network (src/network.rs:197-237) in float64 numpy: the exact-arithmetic yardstick for both f32 paths."""
     d = os.path.join(SCENE, scene_sub)
