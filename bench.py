@@ -96,8 +96,9 @@ def main():
     ap.add_argument("--coarse", type=int, default=64)
     ap.add_argument("--fine", type=int, default=128)
     ap.add_argument("--seed", type=int, default=0)
-    ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
-                    help="MLP arithmetic: f32 = BASELINE's headline config (C3, default); bf16 = the C5 study (not the headline)")
+    ap.add_argument("--dtype", choices=["f32", "bf16", "bf16x3"], default="f32",
+                    help="MLP arithmetic: f32 = BASELINE's headline config (C3, default, f32 MFMA); bf16 = the C5 study (not the headline); "
+                         "bf16x3 = f32-accurate three-way bf16 split on the bf16 matrix cores (opt-in, meets the f32 tolerances)")
     ap.add_argument("--ssaa", type=int, default=1, help="s x s rays per pixel (C5: --dtype bf16 --ssaa 2)")
     ap.add_argument("--skip-empty", action="store_true",
                     help="SURVEY 8f.2 (reported separately, not the headline): skip the colour head of all-empty tiles; "
@@ -189,6 +190,26 @@ def main():
                       "image_bit_identical_to_headline_run": identical,
                       "note": "opt-in skip_empty: colour head skipped for workgroup tiles (128 samples f32, 256 bf16) whose densities are all 0 (exact)"}
         r.kernel_time_query(reset=True)
+    # Reported separately, never part of `value`: the same frame in the opt-in f32-accurate bf16x3 arithmetic.
+    extra_x3 = None
+    if world == 1 and args.dtype == "f32" and not args.skip_empty and not args.no_extra:
+        def x3_step():
+            N.render_image(r.coarse, r.fine, cam, args.fine, seed=args.seed, ssaa=args.ssaa, dtype="bf16x3",
+                           device_out=frame.data_ptr(), stream=stream)
+        step(); torch.cuda.synchronize(dev)
+        ref_frame = frame.clone()
+        x3_step(); torch.cuda.synchronize(dev)
+        diff = (frame - ref_frame).abs()
+        t1 = time.perf_counter()
+        for _ in range(2):
+            x3_step()
+        torch.cuda.synchronize(dev)
+        ms = 1e3 * (time.perf_counter() - t1) / 2
+        extra_x3 = {"rays_per_s": args.width * args.height * args.ssaa * args.ssaa / (ms * 1e-3), "ms_per_step": ms,
+                    "max_abs_diff_vs_f32_frame": float(diff.max().item()), "mean_abs_diff_vs_f32_frame": float(diff.mean().item()),
+                    "note": "opt-in mlp_dtype bf16x3: every f32 product as the six significant bf16 x bf16 products of three-way splits, "
+                            "f32 accumulate; passes the f32 path's tolerances against the oracle (tests/test_gpu_parity.py)"}
+        r.kernel_time_query(reset=True)
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     if use_dist:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -198,36 +219,46 @@ def main():
         n_rays = args.width * args.height * args.ssaa * args.ssaa
         flop_ray = N.flop_per_ray(args.coarse, args.fine)
         bf16 = args.dtype == "bf16"
-        peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_FP32_MFMA_TFLOPS
+        x3 = args.dtype == "bf16x3"
+        peak = PEAK_BF16_MFMA_TFLOPS if (bf16 or x3) else PEAK_FP32_MFMA_TFLOPS
+        mfma_per_flop = 6.0 if x3 else 1.0  # executed bf16 MFMA flops per algorithmic f32 flop
         value = n_rays * args.steps * (world if weak else 1) / dt  # whole-job rays/s over all ranks
         # executed flops of the dominant launches: a skipped sample still runs dense0..7 + alpha (sigma-only cost)
         flops_dom = pts_dom * N.FLOP_PER_POINT_FULL - n_dom * skipped_per_launch * (N.FLOP_PER_POINT_FULL - N.FLOP_PER_POINT_SIGMA)
-        ach = flops_dom / (ms_dom * 1e-3) / 1e12 if ms_dom > 0 else 0.0
+        ach = mfma_per_flop * flops_dom / (ms_dom * 1e-3) / 1e12 if ms_dom > 0 else 0.0
         line = {  # noqa: E501
             "metric": "rays/sec, lego 800x800 (64 coarse + 128 fine samples per ray)", "value": value, "unit": "rays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
             "higher_is_better": True, "scaling": "weak" if weak else "strong", "vs_baseline": None,
-            "dtype": "bf16 operands / f32 accumulate (C5 study, PSNR-level parity)" if bf16 else "f32",
+            "dtype": ("bf16 operands / f32 accumulate (C5 study, PSNR-level parity)" if bf16 else
+                      "f32 as three-way bf16 split: 6 bf16 MFMA products per f32 product, f32 accumulate (f32-level parity)" if x3 else "f32"),
             "data": "real lego weights (lego_rust/, 2 x 595,844 f32 parameters) + tf_reference_samples.json camera; "
                     "sample positions from the seeded counter RNG (no dataset involved)",
-            "config": {"workload": (f"C5-style: {args.ssaa}x{args.ssaa} SSAA, bf16 MLP, " if bf16 or args.ssaa > 1 else "C3: ") +
+            "config": {"workload": (f"C5-style: {args.ssaa}x{args.ssaa} SSAA, bf16 MLP, " if bf16 or args.ssaa > 1 else "C3 (bf16x3 arithmetic): " if x3 else "C3: ") +
                                    f"lego coarse+fine hierarchical, {args.width}x{args.height}, {args.coarse}+{args.fine} "
                                    f"samples/ray, {args.dtype}, {world}xMI355X" +
                                    ("" if world == 1 else ", one frame per rank, no collective" if weak else ", row bands + RCCL all-gather"),
                        "rays_per_step": n_rays, "flop_per_ray": flop_ray, "seed": args.seed,
                        "skip_empty": bool(args.skip_empty), "colour_head_skipped_samples_per_frame": skipped_per_launch,
-                       "whole_job_fraction_of_mfma_roofline": value * flop_ray / (world * peak * 1e12)},  # per-GPU average
+                       "whole_job_fraction_of_mfma_roofline": mfma_per_flop * value * flop_ray / (world * peak * 1e12)},  # per-GPU average
             "roofline": {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
                          "frac": ach / peak, "traffic": pmc_traffic_bytes(("void nerf_mlp_kernel_bf16<true" if os.environ.get("NERF_BF16_KERNEL") == "v1"
-                                                        else "void nerf_mlp_kernel_bf16v2<true") if bf16 else "void nerf_mlp_kernel<true"),
+                                                        else "void nerf_mlp_kernel_bf16v2<true") if bf16 else
+                                                       "void nerf_mlp_kernel_bf16x3<true" if x3 else "void nerf_mlp_kernel<true"),
                          "kernel": (("nerf_mlp_kernel_bf16" if os.environ.get("NERF_BF16_KERNEL") == "v1" else "nerf_mlp_kernel_bf16v2") if bf16
-                                    else "nerf_mlp_kernel") + "<FULL=true, MODE_RAYS> (fine network)",
+                                    else "nerf_mlp_kernel_bf16x3" if x3 else "nerf_mlp_kernel") + "<FULL=true, MODE_RAYS> (fine network)",
                          "launches": n_dom, "avg_launch_ms": ms_dom / max(n_dom, 1),
                          "points_per_launch": pts_dom // max(n_dom, 1), "flop_per_point": N.FLOP_PER_POINT_FULL},
         }
+        if x3:
+            line["roofline"]["note"] = ("achieved/peak price the EXECUTED bf16 MFMA flops (6 per algorithmic f32 flop) against the bf16 peak; "
+                                        "f32_equivalent_tflops = algorithmic f32 flops / time")
+            line["roofline"]["f32_equivalent_tflops"] = ach / 6.0
+        if extra_x3:
+            line["extra_bf16x3"] = extra_x3
         if extra_skip:
             line["extra_skip_empty"] = extra_skip
-        if world == 1 and not args.no_cpu_baseline and not bf16:
+        if world == 1 and not args.no_cpu_baseline and not bf16 and not x3:
             line["cpu_baseline"] = cpu_baseline(args.width, args.height, args.coarse, args.fine, args.seed, args.cpu_naive)
         print(json.dumps(line), flush=True)
     del out

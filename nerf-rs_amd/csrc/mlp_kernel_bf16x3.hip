@@ -84,18 +84,23 @@ __device__ __forceinline__ void pipe_start(PipeX &P) {
     for (int s = 0; s < 3; ++s) P.a[s] = *(const LDS_AS u32x4 *)(P.rd_base + s * 1024);
 }
 
-// Unit U (0..7 within its chunk) begins: hand out its three A fragments, prefetch the next unit's.  Unit 4: the chunk after
-// this one must have landed (every wave waits for its own pieces, then the barrier) and the slot of the previous chunk may be
-// refilled.
+// Unit U (0..7 within its chunk) begins: hand out its three A fragments.  Unit 4: the chunk after this one must have landed
+// (every wave waits for its own pieces, then the barrier) and the slot of the previous chunk may be refilled.
 template <int U>
-__device__ __forceinline__ void pipe_unit(PipeX &P, bf16x8 &a1, bf16x8 &a2, bf16x8 &a3) {
+__device__ __forceinline__ void pipe_take(PipeX &P, bf16x8 &a1, bf16x8 &a2, bf16x8 &a3) {
     if constexpr (U == 4) {
         asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
         pipe_next_chunk(P);
     }
-    constexpr int cur = (U & 1) * 3, nxt = ((U + 1) & 1) * 3;
+    constexpr int cur = (U & 1) * 3;
     asm volatile("" : "+v"(P.a[cur]), "+v"(P.a[cur + 1]), "+v"(P.a[cur + 2])); // one s_waitcnt for the three fragments
     a1 = __builtin_bit_cast(bf16x8, P.a[cur]); a2 = __builtin_bit_cast(bf16x8, P.a[cur + 1]); a3 = __builtin_bit_cast(bf16x8, P.a[cur + 2]);
+}
+
+// start fetching the next unit's fragments (issued behind the first MFMA of unit U: five MFMAs of latency cover)
+template <int U>
+__device__ __forceinline__ void pipe_prefetch(PipeX &P) {
+    constexpr int nxt = ((U + 1) & 1) * 3;
     if constexpr (U == 7) {
         uint32_t off = P.rd_slot_off + kCB;
         off = (off == kRS * kCB) ? 0u : off;
@@ -135,14 +140,36 @@ __device__ __forceinline__ void split_pair(float x0, float x1, uint32_t &h, uint
     l = __builtin_bit_cast(uint32_t, __builtin_convertvector(r2, bf16x2));
 }
 
-// pair Q (0..3) of k-step KS (0/1) of an input tile: registers 8 KS + 2 Q, + 1
+// The same split in four stages of about four VALU instructions, one per MFMA gap (an MFMA gap hides ~5 instructions).
+struct PrepState { f32x2 x; uint32_t h, m; };
+
+template <bool RELU, int KS, int Q, int STAGE>
+__device__ __forceinline__ void prep_stage(const f32x16 &in, B3 &b, PrepState &st) {
+    if constexpr (STAGE == 0) {
+        float x0 = in[8 * KS + 2 * Q], x1 = in[8 * KS + 2 * Q + 1];
+        asm volatile("" : "+v"(x0), "+v"(x1)); // keep the accumulator reads here (hipcc otherwise hoists a whole layer's)
+        if (RELU) { x0 = relu(x0); x1 = relu(x1); }
+        st.x = f32x2{x0, x1};
+    } else if constexpr (STAGE == 1) {
+        st.h = __builtin_bit_cast(uint32_t, __builtin_convertvector(st.x, bf16x2));
+        const f32x2 hf = {__builtin_bit_cast(float, st.h << 16), __builtin_bit_cast(float, st.h & 0xffff0000u)};
+        st.x = st.x - hf;
+    } else if constexpr (STAGE == 2) {
+        st.m = __builtin_bit_cast(uint32_t, __builtin_convertvector(st.x, bf16x2));
+        const f32x2 mf = {__builtin_bit_cast(float, st.m << 16), __builtin_bit_cast(float, st.m & 0xffff0000u)};
+        st.x = st.x - mf;
+    } else {
+        b.h[Q] = st.h; b.m[Q] = st.m;
+        b.l[Q] = __builtin_bit_cast(uint32_t, __builtin_convertvector(st.x, bf16x2));
+    }
+}
+
+// pair Q (0..3) of k-step KS (0/1) of an input tile: registers 8 KS + 2 Q, + 1 (all stages at once: layer starts)
 template <bool RELU, int KS, int Q>
 __device__ __forceinline__ void prep_pair(const f32x16 &in, B3 &b) {
-    float x0 = in[8 * KS + 2 * Q], x1 = in[8 * KS + 2 * Q + 1];
-    asm volatile("" : "+v"(x0), "+v"(x1)); // keep the accumulator reads here (hipcc otherwise hoists a whole layer's)
-    uint32_t hh, mm, ll;
-    split_pair<RELU>(x0, x1, hh, mm, ll);
-    b.h[Q] = hh; b.m[Q] = mm; b.l[Q] = ll;
+    PrepState st;
+    prep_stage<RELU, KS, Q, 0>(in, b, st); prep_stage<RELU, KS, Q, 1>(in, b, st);
+    prep_stage<RELU, KS, Q, 2>(in, b, st); prep_stage<RELU, KS, Q, 3>(in, b, st);
 }
 
 template <bool RELU, int KS>
@@ -150,43 +177,48 @@ __device__ __forceinline__ void prep_all(const f32x16 &in, B3 &b) {
     prep_pair<RELU, KS, 0>(in, b); prep_pair<RELU, KS, 1>(in, b); prep_pair<RELU, KS, 2>(in, b); prep_pair<RELU, KS, 3>(in, b);
 }
 
-// the six products of one unit, small terms first
-__device__ __forceinline__ void unit_mfma(f32x16 &acc, bf16x8 a1, bf16x8 a2, bf16x8 a3, const B3 &b) {
-    const bf16x8 b1 = __builtin_bit_cast(bf16x8, b.h), b2 = __builtin_bit_cast(bf16x8, b.m), b3 = __builtin_bit_cast(bf16x8, b.l);
-    acc = MFMA16(a3, b1, acc);
-    acc = MFMA16(a2, b2, acc);
-    acc = MFMA16(a1, b3, acc);
-    acc = MFMA16(a2, b1, acc);
-    acc = MFMA16(a1, b2, acc);
-    acc = MFMA16(a1, b1, acc);
-}
+#define X3_PIN() __builtin_amdgcn_sched_barrier(0)
 
-// One k-step: NT units (units U0 .. U0 + NT - 1 of the chunk) with the prepared B `bc`; behind them, pair by pair, the B
-// operand of the NEXT k-step is split from tile `nin` (its k-step NKS) into `bn` -- nothing if !HAS_NEXT.
+// One k-step: NT units (units U0 .. U0 + NT - 1 of the chunk) with the prepared B `bc`.  A unit = the six products of one
+// 32 x 16 weight block, small terms first, on one accumulator chain; the other work rides in its MFMA gaps: the next unit's
+// three ds_reads behind MFMA 1, the LDS-DMA piece behind MFMA 2, and behind MFMAs 3..6 the four stages of splitting one pair
+// of the NEXT k-step's B operand (tile `nin`, k-step NKS, into `bn`; pair q in unit 2 q of an 8-tile layer, unit q of viewdirs).
 template <int NT, int U0, bool HAS_NEXT, bool NRELU, int NKS>
 __device__ __forceinline__ void k_step(f32x16 (&out)[8], const B3 &bc, const f32x16 &nin, B3 &bn, PipeX &P) {
+    const bf16x8 b1 = __builtin_bit_cast(bf16x8, bc.h), b2 = __builtin_bit_cast(bf16x8, bc.m), b3 = __builtin_bit_cast(bf16x8, bc.l);
     static_for<0, NT>([&](auto nt_c) {
         constexpr int nt = decltype(nt_c)::value;
         constexpr int U = U0 + nt;
+        constexpr bool prep = HAS_NEXT && (NT == 4 || (nt & 1) == 0);
+        constexpr int Q = NT == 4 ? nt : nt / 2;
         bf16x8 a1, a2, a3;
-        pipe_unit<U>(P, a1, a2, a3);
-        __builtin_amdgcn_sched_barrier(0);
-        unit_mfma(out[nt], a1, a2, a3, bc);
-        __builtin_amdgcn_sched_barrier(0);
+        PrepState st;
+        pipe_take<U>(P, a1, a2, a3);
+        X3_PIN();
+        out[nt] = MFMA16(a3, b1, out[nt]);
+        X3_PIN();
+        pipe_prefetch<U>(P);
+        X3_PIN();
+        out[nt] = MFMA16(a2, b2, out[nt]);
+        X3_PIN();
         pipe_dma<U>(P);
-        if constexpr (HAS_NEXT) { // pair q behind unit 2 q (8-tile layers) or unit min(q, 2) (viewdirs): done before the last unit
-            if constexpr (NT == 8) {
-                if constexpr (nt == 0) prep_pair<NRELU, NKS, 0>(nin, bn);
-                if constexpr (nt == 2) prep_pair<NRELU, NKS, 1>(nin, bn);
-                if constexpr (nt == 4) prep_pair<NRELU, NKS, 2>(nin, bn);
-                if constexpr (nt == 6) prep_pair<NRELU, NKS, 3>(nin, bn);
-            } else {
-                if constexpr (nt == 0) prep_pair<NRELU, NKS, 0>(nin, bn);
-                if constexpr (nt == 1) prep_pair<NRELU, NKS, 1>(nin, bn);
-                if constexpr (nt == 2) { prep_pair<NRELU, NKS, 2>(nin, bn); prep_pair<NRELU, NKS, 3>(nin, bn); }
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
+        X3_PIN();
+        out[nt] = MFMA16(a1, b3, out[nt]);
+        X3_PIN();
+        if constexpr (prep) prep_stage<NRELU, NKS, Q, 0>(nin, bn, st);
+        X3_PIN();
+        out[nt] = MFMA16(a2, b1, out[nt]);
+        X3_PIN();
+        if constexpr (prep) prep_stage<NRELU, NKS, Q, 1>(nin, bn, st);
+        X3_PIN();
+        out[nt] = MFMA16(a1, b2, out[nt]);
+        X3_PIN();
+        if constexpr (prep) prep_stage<NRELU, NKS, Q, 2>(nin, bn, st);
+        X3_PIN();
+        out[nt] = MFMA16(a1, b1, out[nt]);
+        X3_PIN();
+        if constexpr (prep) prep_stage<NRELU, NKS, Q, 3>(nin, bn, st);
+        X3_PIN();
     });
 }
 
@@ -287,6 +319,8 @@ __global__ __launch_bounds__(256, 1) void nerf_mlp_kernel_bf16x3(const MlpArgs A
     P.gbase = (const char *)A.wstream + wave * 6144;
     __syncthreads();
     pipe_start(P);
+    uint64_t clk0 = 0, rt0 = 0;
+    if (A.clock_out) { clk0 = __builtin_amdgcn_s_memtime(); rt0 = __builtin_amdgcn_s_memrealtime(); }
 
     const int n_tiles = (A.n_points + kPointsPerBlock - 1) / kPointsPerBlock;
     RawIn nxt = load_raw<MODE>(A, blockIdx.x, wave, p);
@@ -359,6 +393,10 @@ __global__ __launch_bounds__(256, 1) void nerf_mlp_kernel_bf16x3(const MlpArgs A
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (A.clock_out && tid == 0) { // diagnostic: shader clock = d(memtime) / d(memrealtime) x 100 MHz
+        A.clock_out[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - clk0;
+        A.clock_out[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - rt0;
+    }
 }
 
 template <bool FULL, int MODE>

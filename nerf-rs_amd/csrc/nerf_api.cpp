@@ -372,7 +372,7 @@ int render_device(nerf_ctx *c, const nerf_camera *cam, const nerf_render_opts *o
         a.n_points = n_rays * M; a.samples_per_ray = M; a.t = t_fine;
         a.sigma_out = c->d_sf; a.rgb_out = c->d_rgbf;
         a.clock_out = c->d_clock; // NULL unless NERF_DEBUG_CLOCK=1
-        c->clock_valid = c->d_clock != nullptr && !(bf16 && c->bf16_v1) && dtype != NERF_MLP_BF16X3; // those kernels write no stamps
+        c->clock_valid = c->d_clock != nullptr && !(bf16 && c->bf16_v1); // the first bf16 design writes no stamps
         {
             Timed t(c, st, 1, (uint64_t)a.n_points, timing);
             HIP_TRY(c, launch_mlp(c, dtype, a, true, st));

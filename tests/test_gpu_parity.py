@@ -597,3 +597,9 @@ def test_gpu_f32_is_as_accurate_as_the_reference_arithmetic(renderer, oracle_net
         gs, gr = err(sg, rgb); os_, or_ = err(osg, orgb)
         assert gs <= 3e-5 and gr <= 8e-6, (gs, gr)
         assert gs <= 2.0 * os_ + 2e-6 and gr <= 2.0 * or_ + 5e-7, ((gs, gr), (os_, or_))
+        # the opt-in bf16x3 arithmetic is held to the same yardstick: not less accurate than the reference's own f32 arithmetic
+        xrgb, xsg = net.forward_batch(g["pts"], g["dirs"], dtype="bf16x3")
+        xs, xr = err(xsg, xrgb)
+        print(f"\n{sub}: error vs float64 (sigma rel, rgb abs)  f32 MFMA {gs:.2e} {gr:.2e} | bf16x3 {xs:.2e} {xr:.2e} | CPU reference arithmetic {os_:.2e} {or_:.2e}")
+        assert xs <= 3e-5 and xr <= 8e-6, (xs, xr)
+        assert xs <= 2.0 * os_ + 2e-6 and xr <= 2.0 * or_ + 5e-7, ((xs, xr), (os_, or_))
