@@ -23,6 +23,11 @@ pub struct nerf_camera {
     pub far: f32,
 }
 
+/// `nerf_render_opts::mlp_dtype` / `nerf_forward_batch_ex`: the MLP arithmetic (include/nerf_mi355x.h).
+pub const NERF_MLP_F32: i32 = 0;
+pub const NERF_MLP_BF16: i32 = 1;
+pub const NERF_MLP_BF16X3: i32 = 2;
+
 #[repr(C)]
 #[derive(Clone, Copy, Debug, Default)]
 pub struct nerf_render_opts {
