@@ -39,10 +39,13 @@ def test_full_frame_c3_matches_oracle(renderer, native, oracle, oracle_nets, sam
     cpu1 = oracle.render_image(*oracle_nets, ocam, oracle.make_opts(64, 128, seed=1, threads=nthr))
     gpu0 = native.render_image(renderer.coarse, renderer.fine, cam, 128, seed=0)
     gpu1 = native.render_image(renderer.coarse, renderer.fine, cam, 128, seed=1)
+    x3_0 = native.render_image(renderer.coarse, renderer.fine, cam, 128, seed=0, dtype="bf16x3")
+    x3_1 = native.render_image(renderer.coarse, renderer.fine, cam, 128, seed=1, dtype="bf16x3")
     b16_0 = native.render_image(renderer.coarse, renderer.fine, cam, 128, seed=0, dtype="bf16")
     b16_1 = native.render_image(renderer.coarse, renderer.fine, cam, 128, seed=1, dtype="bf16")
     d = np.abs(gpu0 - cpu0)
-    q_gpu, q_cpu = native.quantize_rgb8(gpu0), oracle.quantize_rgb8(cpu0)
+    dx = np.abs(x3_0 - cpu0)
+    q_gpu, q_cpu, q_x3 = native.quantize_rgb8(gpu0), oracle.quantize_rgb8(cpu0), native.quantize_rgb8(x3_0)
     rec = {
         "config": f"lego {W}x{H}, 64+128 samples/ray, seed 0, full frame", "cpu_seconds_per_frame": round(t_cpu, 1), "cpu_threads": nthr,
         "f32_max_abs_diff": float(d.max()), "f32_mean_abs_diff": float(d.mean()), "f32_psnr_gpu_vs_cpu_db": psnr(gpu0, cpu0),
@@ -51,6 +54,10 @@ def test_full_frame_c3_matches_oracle(renderer, native, oracle, oracle_nets, sam
         "gate2_cpu_seed1_vs_cpu_seed0_db": psnr(cpu1, cpu0), "gate2_gpu_f32_seed1_vs_cpu_seed0_db": psnr(gpu1, cpu0),
         "gate2_gpu_bf16_seed1_vs_cpu_seed0_db": psnr(b16_1, cpu0), "bf16_vs_cpu_same_seed_db": psnr(b16_0, cpu0),
         "bf16_vs_f32_gpu_same_seed_db": psnr(b16_0, gpu0),
+        "bf16x3_max_abs_diff": float(dx.max()), "bf16x3_mean_abs_diff": float(dx.mean()), "bf16x3_psnr_gpu_vs_cpu_db": psnr(x3_0, cpu0),
+        "bf16x3_fraction_above_5e-5": float((dx > 5e-5).mean()), "bf16x3_p9999_abs_diff": float(np.quantile(dx, 0.9999)),
+        "bf16x3_rgb8_equal_fraction": float((q_x3 == q_cpu).mean()), "bf16x3_rgb8_max_step": int(np.abs(q_x3.astype(int) - q_cpu.astype(int)).max()),
+        "gate2_gpu_bf16x3_seed1_vs_cpu_seed0_db": psnr(x3_1, cpu0),
     }
     print("\nFULLFRAME " + json.dumps(rec))
     assert np.isfinite(gpu0).all() and np.isfinite(b16_0).all()
@@ -59,3 +66,7 @@ def test_full_frame_c3_matches_oracle(renderer, native, oracle, oracle_nets, sam
     assert abs(rec["gate2_gpu_f32_seed1_vs_cpu_seed0_db"] - rec["gate2_cpu_seed1_vs_cpu_seed0_db"]) <= 0.1
     assert abs(rec["gate2_gpu_bf16_seed1_vs_cpu_seed0_db"] - rec["gate2_cpu_seed1_vs_cpu_seed0_db"]) <= 0.1
     assert rec["bf16_vs_f32_gpu_same_seed_db"] >= 45.0
+    # the opt-in bf16x3 arithmetic is held to the f32 path's bounds
+    assert rec["bf16x3_max_abs_diff"] <= 2e-2 and rec["bf16x3_fraction_above_5e-5"] <= 1e-3 and rec["bf16x3_psnr_gpu_vs_cpu_db"] >= 80.0
+    assert rec["bf16x3_rgb8_equal_fraction"] >= 0.9999 and rec["bf16x3_rgb8_max_step"] <= 2
+    assert abs(rec["gate2_gpu_bf16x3_seed1_vs_cpu_seed0_db"] - rec["gate2_cpu_seed1_vs_cpu_seed0_db"]) <= 0.1
