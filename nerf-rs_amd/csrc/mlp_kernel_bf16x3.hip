@@ -14,7 +14,7 @@
 // is split on the fly: 8 f32 values per lane -> ReLU -> three packed bf16x8 fragments (about 60 VALU, prepared one k-step
 // ahead, spread behind the MFMAs of the current k-step).  Weights are split on the host.
 // Stream (mlp_layout.h): per layer, input tile, k-step and output tile one UNIT = three 1-KiB pieces (w1, w2, w3 fragments of
-// the same 32 x 16 block); a k-step of an 8-tile layer = 24 pieces = one 24-KiB chunk; 3-slot ring; sync at unit 4 of a chunk;
+// the same 32 x 16 block); a k-step of an 8-tile layer = 24 pieces = one 24-KiB chunk; ring of kRingSlotsX3 slots; sync at unit 4 of a chunk;
 // each wave DMA's its six pieces of the chunk after next behind units 4, 5, 6, 7, 0, 1.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -65,15 +65,18 @@ __device__ __forceinline__ void pipe_next_chunk(PipeX &P) {
     P.wr_slot_off = (slot == kRS * kCB) ? 0u : slot;
 }
 
-// (Re)start at chunk 0 in the state a steady-state run is in there: chunk 0 landed, chunk 1 selected with the four pieces
-// that units 4..7 of "chunk -1" would have issued (units 0, 1 of chunk 0 issue pieces 4, 5), unit 0 prefetched.  The caller
-// guarantees that no wave still reads the ring.
+// (Re)start at chunk 0 in the state a steady-state run is in there: chunks 0 .. kRS - 3 landed, chunk kRS - 2 selected with
+// the four pieces that units 4..7 of "chunk -1" would have issued (units 0, 1 of chunk 0 issue pieces 4, 5), unit 0
+// prefetched.  The caller guarantees that no wave still reads the ring.
 __device__ __forceinline__ void pipe_start(PipeX &P) {
     P.next_off = 0;
     P.wr_slot_off = 0;
-    pipe_next_chunk(P);
 #pragma unroll
-    for (int i = 0; i < 6; ++i) glds_piece(P.lane16, P.cur_src + i * 1024, P.cur_dst + i * 1024);
+    for (int c = 0; c < kRS - 2; ++c) {
+        pipe_next_chunk(P);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) glds_piece(P.lane16, P.cur_src + i * 1024, P.cur_dst + i * 1024);
+    }
     pipe_next_chunk(P);
 #pragma unroll
     for (int i = 0; i < 4; ++i) glds_piece(P.lane16, P.cur_src + i * 1024, P.cur_dst + i * 1024);
@@ -85,11 +88,13 @@ __device__ __forceinline__ void pipe_start(PipeX &P) {
 }
 
 // Unit U (0..7 within its chunk) begins: hand out its three A fragments.  Unit 4: the chunk after this one must have landed
-// (every wave waits for its own pieces, then the barrier) and the slot of the previous chunk may be refilled.
+// (every wave waits for its own pieces, then the barrier) and the slot of the previous chunk is refilled with chunk c + kRS - 1.
 template <int U>
 __device__ __forceinline__ void pipe_take(PipeX &P, bf16x8 &a1, bf16x8 &a2, bf16x8 &a3) {
     if constexpr (U == 4) {
-        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        // chunk c + 1 must have landed; the six pieces of each of the kRS - 3 chunks issued after it may still be in flight
+        // (VMEM returns in order; a compiler-issued access in between only makes this wait longer)
+        asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(6 * (kRS - 3)) : "memory");
         pipe_next_chunk(P);
     }
     constexpr int cur = (U & 1) * 3;

@@ -77,7 +77,10 @@ constexpr int kPointsPerBlockBf16V2 = 256;
 // (layer, input tile, k-step, output tile), each followed by the pieces of the second and third bf16 part of the same
 // weights: a unit = 3 KiB, a k-step of an 8-tile layer = 24 KiB = one chunk, a k-step of viewdirs half a chunk.  No padding.
 constexpr int kChunkBytesX3 = 24576;
-constexpr int kRingSlotsX3 = 3;
+#ifndef NERF_X3_RING_SLOTS
+#define NERF_X3_RING_SLOTS 3
+#endif
+constexpr int kRingSlotsX3 = NERF_X3_RING_SLOTS; // 3..5 (measured equal: the kernel is power-limited, not latency-limited)
 constexpr int kChunksSigmaX3 = 2 * 2 + 4 * 16 + 20 + 2 * 16;  // dense0 (2 tiles x 2 k-steps), dense1-4, dense5, dense6-7 = 120
 constexpr int kChunksFullX3 = kChunksSigmaX3 + 16 + 9;        // + bottleneck + viewdirs (9 tiles, one chunk each) = 145
 constexpr int kLdsBytesX3 = kRingSlotsX3 * kChunkBytesX3 + kSmallBytes;
