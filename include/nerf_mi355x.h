@@ -118,6 +118,9 @@ int nerf_check_network_dir(const char *dir);
  * buffers to query the lengths (in floats).  Host-only. */
 int nerf_debug_pack_network_dir(const char *dir, float *wstream, size_t wstream_cap, float *small, size_t small_cap,
                                 size_t *wstream_len, size_t *small_len);
+/* Diagnostic: the three bf16 parts (raw bit patterns) the NERF_MLP_BF16X3 packer stores for each of n f32 weights:
+ * parts[3 i + k], k = 0..2, with v = p0 + p1 + p2 up to 2^-27 |v|.  Host-only. */
+int nerf_debug_split_bf16x3(const float *values, size_t n, uint16_t *parts /* 3 n */);
 
 /* ---- S2: Network::forward_batch (src/network.rs:197-237) -------------------------------------------------- */
 /* host pointers, synchronous.  n == 0 is a no-op (src/network.rs:199-201). */

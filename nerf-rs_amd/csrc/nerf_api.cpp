@@ -600,6 +600,12 @@ int nerf_check_network_dir(const char *dir) {
     return NERF_OK;
 }
 
+int nerf_debug_split_bf16x3(const float *values, size_t n, uint16_t *parts) {
+    if ((!values || !parts) && n) return fail(nullptr, NERF_ERR_INVALID, "NULL argument");
+    for (size_t i = 0; i < n; ++i) split_bf16x3(values[i], parts + 3 * i);
+    return NERF_OK;
+}
+
 int nerf_debug_pack_network_dir(const char *dir, float *wstream, size_t wstream_cap, float *small, size_t small_cap,
                                 size_t *wstream_len, size_t *small_len) {
     if (!dir) return fail(nullptr, NERF_ERR_INVALID, "dir is NULL");

@@ -335,6 +335,10 @@ def test_packed_blob_loads_identically(renderer, native, tmp_path):
             ref = (renderer.coarse if which == 0 else renderer.fine).forward_batch(g["pts"], g["dirs"])
             out = net.forward_batch(g["pts"], g["dirs"])
             assert np.array_equal(out[0], ref[0]) and np.array_equal(out[1], ref[1])
+            for dt in ("bf16", "bf16x3"):   # the bf16-family streams are rebuilt from the blob's f32 stream: same bits as from the directory
+                ref_d = (renderer.coarse if which == 0 else renderer.fine).forward_batch(g["pts"], g["dirs"], dtype=dt)
+                out_d = net.forward_batch(g["pts"], g["dirs"], dtype=dt)
+                assert np.array_equal(out_d[0], ref_d[0]) and np.array_equal(out_d[1], ref_d[1]), dt
         bad = tmp_path / "bad.nrf"; bad.write_bytes(b"NRFMI355" + b"\0" * 64)
         with pytest.raises(native.NerfError):
             native.load_network_blob(r2, 0, bad)
