@@ -125,7 +125,21 @@ __device__ __forceinline__ void pipe_dma(PipeX &P) {
     else if constexpr (U <= 1) glds_piece(P.lane16, P.cur_src + (U + 4) * 1024, P.cur_dst + (U + 4) * 1024);
 }
 
+#ifndef NERF_X3_DIAG_MFMA_16X16
+#define NERF_X3_DIAG_MFMA_16X16 0 // timing/power experiment only (results are garbage): the same FLOPs as two 16x16x32 MFMAs
+#endif
+#if NERF_X3_DIAG_MFMA_16X16
+__device__ __forceinline__ f32x16 mfma_as_two_16x16(bf16x8 a, bf16x8 b, f32x16 c) {
+    f32x4 lo = {c[0], c[1], c[2], c[3]}, hi = {c[4], c[5], c[6], c[7]};
+    lo = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, lo, 0, 0, 0);
+    hi = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, hi, 0, 0, 0);
+    c[0] = lo[0]; c[1] = lo[1]; c[2] = lo[2]; c[3] = lo[3]; c[4] = hi[0]; c[5] = hi[1]; c[6] = hi[2]; c[7] = hi[3];
+    return c;
+}
+#define MFMA16(a, b, c) mfma_as_two_16x16((a), (b), (c))
+#else
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
+#endif
 
 struct B3 { u32x4 h, m, l; }; // the three bf16x8 fragments of one k-step's B operand
 
