@@ -35,6 +35,10 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 namespace {
 
 constexpr int kCB = kChunkBytesX3, kRS = kRingSlotsX3;
+#ifndef NERF_X3_AHEAD
+#define NERF_X3_AHEAD 2
+#endif
+constexpr int kX3Ahead = NERF_X3_AHEAD; // operand prefetch distance in units (1..3); a unit is six MFMAs = 192 cycles
 
 template <int I, int N, class F>
 __device__ __forceinline__ void static_for(F &&f) {
@@ -48,7 +52,7 @@ struct PipeX {
     const LDS_AS char *rd_base;   // LDS address (incl. lane * 16) of the chunk the next prefetched unit lives in
     const LDS_AS char *ring_lane;
     uint32_t rd_slot_off;
-    u32x4 a[6];                   // A fragments (w1, w2, w3) of the current unit [parity] and the next one
+    u32x4 a[12];                  // A fragments (w1, w2, w3) of four consecutive units (slot = unit & 3): current, kX3Ahead in flight
     uint32_t ring_addr, wr_slot_off, next_off, stream_bytes;
     const char *gbase, *cur_src;
     uint32_t cur_dst, lane16;
@@ -84,7 +88,7 @@ __device__ __forceinline__ void pipe_start(PipeX &P) {
     P.rd_slot_off = 0;
     P.rd_base = P.ring_lane;
 #pragma unroll
-    for (int s = 0; s < 3; ++s) P.a[s] = *(const LDS_AS u32x4 *)(P.rd_base + s * 1024);
+    for (int s = 0; s < 3 * kX3Ahead; ++s) P.a[s] = *(const LDS_AS u32x4 *)(P.rd_base + s * 1024);
 }
 
 // Unit U (0..7 within its chunk) begins: hand out its three A fragments.  Unit 4: the chunk after this one must have landed
@@ -97,22 +101,22 @@ __device__ __forceinline__ void pipe_take(PipeX &P, bf16x8 &a1, bf16x8 &a2, bf16
         asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(6 * (kRS - 3)) : "memory");
         pipe_next_chunk(P);
     }
-    constexpr int cur = (U & 1) * 3;
+    constexpr int cur = (U & 3) * 3;
     asm volatile("" : "+v"(P.a[cur]), "+v"(P.a[cur + 1]), "+v"(P.a[cur + 2])); // one s_waitcnt for the three fragments
     a1 = __builtin_bit_cast(bf16x8, P.a[cur]); a2 = __builtin_bit_cast(bf16x8, P.a[cur + 1]); a3 = __builtin_bit_cast(bf16x8, P.a[cur + 2]);
 }
 
-// start fetching the next unit's fragments (issued behind the first MFMA of unit U: five MFMAs of latency cover)
+// start fetching the fragments of unit U + kX3Ahead (issued behind the first MFMA of unit U)
 template <int U>
 __device__ __forceinline__ void pipe_prefetch(PipeX &P) {
-    constexpr int nxt = ((U + 1) & 1) * 3;
-    if constexpr (U == 7) {
+    constexpr int nxt = ((U + kX3Ahead) & 3) * 3;
+    if constexpr (U + kX3Ahead == 8) { // the unit to fetch opens the next chunk
         uint32_t off = P.rd_slot_off + kCB;
         off = (off == kRS * kCB) ? 0u : off;
         P.rd_slot_off = off;
         P.rd_base = P.ring_lane + off;
     }
-    constexpr int nu = (U + 1) & 7;
+    constexpr int nu = (U + kX3Ahead) & 7;
 #pragma unroll
     for (int s = 0; s < 3; ++s) P.a[nxt + s] = *(const LDS_AS u32x4 *)(P.rd_base + (3 * nu + s) * 1024);
 }
