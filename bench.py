@@ -131,7 +131,11 @@ def main():
     if use_dist:
         if world == 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)  # nccl == RCCL on ROCm
+        backend = os.environ.get("NERF_BENCH_BACKEND", "nccl")  # nccl == RCCL on ROCm; "gloo" only to rehearse N > 1 on ONE GPU
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     scene = os.path.join(ROOT, "lego_rust")
     r = N.Renderer(dev_index)
@@ -211,7 +215,7 @@ def main():
                     "note": "opt-in mlp_dtype bf16x3: every f32 product as the six significant bf16 x bf16 products of three-way splits, "
                             "f32 accumulate; passes the f32 path's tolerances against the oracle (tests/test_gpu_parity.py)"}
         r.kernel_time_query(reset=True)
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev if not use_dist or dist.get_backend() == "nccl" else "cpu")
     if use_dist:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())

@@ -43,9 +43,17 @@ def render_image_distributed(coarse, fine, camera, fine_samples_per_ray=128, *, 
             stream = torch.cuda.current_stream(dev).cuda_stream
             render_image(coarse, fine, camera, fine_samples_per_ray, seed=seed, coarse_only=coarse_only, crop=band_crop,
                          ssaa=ssaa, dtype=dtype, skip_empty=skip_empty, device_out=band.data_ptr(), stream=stream)
-    gathered = torch.empty((world, max_rows, w, 3), dtype=torch.float32, device=band.device)
-    dist.all_gather_into_tensor(gathered.view(-1), band.view(-1), group=group) if band.device.type == "cuda" else \
-        dist.all_gather(list(gathered.unbind(0)), band, group=group)
+    if band.device.type == "cuda" and dist.get_backend(group) != "nccl":
+        # rehearsal only (e.g. gloo with several ranks on one GPU): the collective runs on host copies of the bands
+        torch.cuda.current_stream(band.device).synchronize()
+        host = band.cpu()
+        parts = [torch.empty_like(host) for _ in range(world)]
+        dist.all_gather(parts, host, group=group)
+        gathered = torch.stack(parts).to(band.device)
+    else:
+        gathered = torch.empty((world, max_rows, w, 3), dtype=torch.float32, device=band.device)
+        dist.all_gather_into_tensor(gathered.view(-1), band.view(-1), group=group) if band.device.type == "cuda" else \
+            dist.all_gather(list(gathered.unbind(0)), band, group=group)
     if h % world == 0:
         frame = gathered.view(h, w, 3)
     else:
