@@ -54,15 +54,31 @@ struct PipeX {
     uint32_t rd_slot_off;
     u32x4 a[12];                  // A fragments (w1, w2, w3) of four consecutive units (slot = unit & 3): current, kX3Ahead in flight
     uint32_t ring_addr, wr_slot_off, next_off, stream_bytes;
-    const char *gbase, *cur_src;
-    uint32_t cur_dst, lane16;
+    const char *gbase, *cur_src, *cur_src_hi; // cur_src_hi = cur_src + 4 KiB: pieces 4, 5 (instruction offsets reach 4095)
+    uint32_t cur_dst, cur_dst_hi, lane16;
 };
+
+// LDS-DMA piece whose instruction offset OFF advances the global AND the LDS address (both = base + OFF + lane * 16)
+template <int OFF>
+__device__ __forceinline__ void glds_piece_off(uint32_t lane16, const char *gsrc, uint32_t dst) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\t"
+                 "s_mov_b32 m0, %3\n\t"
+                 "s_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, %2 offset:%4\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(lane16), "s"(gsrc), "s"(dst), "n"(OFF)
+                 : "memory");
+}
 
 __device__ __forceinline__ void pipe_next_chunk(PipeX &P) {
     uint32_t off = P.next_off, slot = P.wr_slot_off;
     asm volatile("" : "+s"(off), "+s"(slot));
     P.cur_src = P.gbase + off;
     P.cur_dst = P.ring_addr + slot;
+    P.cur_src_hi = P.cur_src + 4096;
+    P.cur_dst_hi = P.cur_dst + 4096;
     off += kCB;
     P.next_off = (off == P.stream_bytes) ? 0u : off;
     slot += kCB;
@@ -101,8 +117,8 @@ __device__ __forceinline__ void pipe_take(PipeX &P, bf16x8 &a1, bf16x8 &a2, bf16
         asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(6 * (kRS - 3)) : "memory");
         pipe_next_chunk(P);
     }
-    constexpr int cur = (U & 3) * 3;
-    asm volatile("" : "+v"(P.a[cur]), "+v"(P.a[cur + 1]), "+v"(P.a[cur + 2])); // one s_waitcnt for the three fragments
+    constexpr int cur = (U & 3) * 3; // the unit's first MFMA takes the fragment that was read LAST (w3): LDS returns in order, so
+                                     // hipcc's one s_waitcnt for it covers all three
     a1 = __builtin_bit_cast(bf16x8, P.a[cur]); a2 = __builtin_bit_cast(bf16x8, P.a[cur + 1]); a3 = __builtin_bit_cast(bf16x8, P.a[cur + 2]);
 }
 
@@ -125,8 +141,8 @@ __device__ __forceinline__ void pipe_prefetch(PipeX &P) {
 // U 4 -> 0, 5 -> 1, 6 -> 2, 7 -> 3, 0 -> 4, 1 -> 5
 template <int U>
 __device__ __forceinline__ void pipe_dma(PipeX &P) {
-    if constexpr (U >= 4) glds_piece(P.lane16, P.cur_src + (U - 4) * 1024, P.cur_dst + (U - 4) * 1024);
-    else if constexpr (U <= 1) glds_piece(P.lane16, P.cur_src + (U + 4) * 1024, P.cur_dst + (U + 4) * 1024);
+    if constexpr (U >= 4) glds_piece_off<(U - 4) * 1024>(P.lane16, P.cur_src, P.cur_dst);
+    else if constexpr (U <= 1) glds_piece_off<U * 1024>(P.lane16, P.cur_src_hi, P.cur_dst_hi);
 }
 
 #ifndef NERF_X3_DIAG_MFMA_16X16
