@@ -38,3 +38,6 @@ hipError_t nerf_mlp_bf16v2_launch(const MlpArgs &a, bool full, int n_blocks, hip
 // f32 by three-way bf16 split (mlp_kernel_bf16x3.hip): a.wstream is the three-part stream (mlp_layout.h kChunks*X3)
 hipError_t nerf_mlp_bf16x3_init();
 hipError_t nerf_mlp_bf16x3_launch(const MlpArgs &a, bool full, int n_blocks, hipStream_t stream);
+// the same arithmetic on v_mfma_f32_16x16x32_bf16 (mlp_kernel_bf16x3b.hip): its own stream permutation, small params in feature order
+hipError_t nerf_mlp_bf16x3b_init();
+hipError_t nerf_mlp_bf16x3b_launch(const MlpArgs &a, bool full, int n_blocks, hipStream_t stream);

@@ -549,6 +549,27 @@ def test_bf16x3_forward_meets_f32_tolerances(renderer, samples, oracle_nets):
         _close_mlp(rgb, sg, ergb, esg)
 
 
+def test_bf16x3_16x16_tiling_experiment(renderer, native):
+    """mlp_kernel_bf16x3b.hip (NERF_X3_KERNEL=b): the same arithmetic on v_mfma_f32_16x16x32_bf16 -- its own register layout,
+    weight-stream permutation, encoding slot order and small-parameter order.  Kept as a measured experiment (DESIGN 4.5:
+    +1.3 % rays/s, sigma error 3.5e-5 instead of 1.4e-5): it must stay inside the f32 gates and agree with the default tiling."""
+    g = golden("forward_batch_4096.npz")
+    os.environ["NERF_X3_KERNEL"] = "b"
+    try:
+        with native.Renderer(0) as rb:
+            rb.load_scene(SCENE)
+            for name, net, ref_net in (("coarse", rb.coarse, renderer.coarse), ("fine", rb.fine, renderer.fine)):
+                rgb, sg = net.forward_batch(g["pts"], g["dirs"], dtype="bf16x3")
+                _close_mlp(rgb, sg, g[f"{name}_rgb"], g[f"{name}_sigma"])
+                rrgb, rsg = ref_net.forward_batch(g["pts"], g["dirs"], dtype="bf16x3")
+                assert (np.abs(sg - rsg) / (1 + np.abs(rsg))).max() <= 1e-4 and np.abs(rgb - rrgb).max() <= 2e-5
+                for n in (1, 17, 33, 129):
+                    r2, s2 = net.forward_batch(g["pts"][:, :n], g["dirs"][:n], dtype="bf16x3")
+                    assert np.array_equal(s2, sg[:n]) and np.array_equal(r2, rgb[:n])
+    finally:
+        del os.environ["NERF_X3_KERNEL"]
+
+
 def test_bf16x3_render_matches_oracle_crop(renderer, native, samples):
     """The C3 crop (800x800, 64 + 128) through the bf16x3 arithmetic: the f32 path's frame tolerance, and skip_empty exact."""
     cam = native.camera_from_samples(samples, 800, 800, 64)
