@@ -33,100 +33,9 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 namespace {
 
 constexpr int kCB = kChunkBytesX3, kRS = kRingSlotsX3;
-constexpr int kAheadB = 1; // operand prefetch distance in units
+constexpr int kX3Ahead = 1; // operand prefetch distance in units
 
-template <int I, int N, class F>
-__device__ __forceinline__ void static_for(F &&f) {
-    if constexpr (I < N) {
-        f(std::integral_constant<int, I>{});
-        static_for<I + 1, N>(f);
-    }
-}
-
-struct PipeX {
-    const LDS_AS char *rd_base;
-    const LDS_AS char *ring_lane;
-    uint32_t rd_slot_off;
-    u32x4 a[12];
-    uint32_t ring_addr, wr_slot_off, next_off, stream_bytes;
-    const char *gbase, *cur_src, *cur_src_hi;
-    uint32_t cur_dst, cur_dst_hi, lane16;
-};
-
-template <int OFF>
-__device__ __forceinline__ void glds_piece_off(uint32_t lane16, const char *gsrc, uint32_t dst) {
-    uint32_t keep;
-    asm volatile("s_mov_b32 %0, m0\n\t"
-                 "s_mov_b32 m0, %3\n\t"
-                 "s_nop 0\n\t"
-                 "global_load_lds_dwordx4 %1, %2 offset:%4\n\t"
-                 "s_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(lane16), "s"(gsrc), "s"(dst), "n"(OFF)
-                 : "memory");
-}
-
-__device__ __forceinline__ void pipe_next_chunk(PipeX &P) {
-    uint32_t off = P.next_off, slot = P.wr_slot_off;
-    asm volatile("" : "+s"(off), "+s"(slot));
-    P.cur_src = P.gbase + off;
-    P.cur_dst = P.ring_addr + slot;
-    P.cur_src_hi = P.cur_src + 4096;
-    P.cur_dst_hi = P.cur_dst + 4096;
-    off += kCB;
-    P.next_off = (off == P.stream_bytes) ? 0u : off;
-    slot += kCB;
-    P.wr_slot_off = (slot == kRS * kCB) ? 0u : slot;
-}
-
-__device__ __forceinline__ void pipe_start(PipeX &P) {
-    P.next_off = 0;
-    P.wr_slot_off = 0;
-#pragma unroll
-    for (int c = 0; c < kRS - 2; ++c) {
-        pipe_next_chunk(P);
-#pragma unroll
-        for (int i = 0; i < 6; ++i) glds_piece(P.lane16, P.cur_src + i * 1024, P.cur_dst + i * 1024);
-    }
-    pipe_next_chunk(P);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) glds_piece(P.lane16, P.cur_src + i * 1024, P.cur_dst + i * 1024);
-    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-    P.rd_slot_off = 0;
-    P.rd_base = P.ring_lane;
-#pragma unroll
-    for (int s = 0; s < 3 * kAheadB; ++s) P.a[s] = *(const LDS_AS u32x4 *)(P.rd_base + s * 1024);
-}
-
-template <int U>
-__device__ __forceinline__ void pipe_take(PipeX &P, bf16x8 &a1, bf16x8 &a2, bf16x8 &a3) {
-    if constexpr (U == 4) {
-        asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(6 * (kRS - 3)) : "memory");
-        pipe_next_chunk(P);
-    }
-    constexpr int cur = (U & 3) * 3;
-    a1 = __builtin_bit_cast(bf16x8, P.a[cur]); a2 = __builtin_bit_cast(bf16x8, P.a[cur + 1]); a3 = __builtin_bit_cast(bf16x8, P.a[cur + 2]);
-}
-
-template <int U>
-__device__ __forceinline__ void pipe_prefetch(PipeX &P) {
-    constexpr int nxt = ((U + kAheadB) & 3) * 3;
-    if constexpr (U + kAheadB == 8) {
-        uint32_t off = P.rd_slot_off + kCB;
-        off = (off == kRS * kCB) ? 0u : off;
-        P.rd_slot_off = off;
-        P.rd_base = P.ring_lane + off;
-    }
-    constexpr int nu = (U + kAheadB) & 7;
-#pragma unroll
-    for (int s = 0; s < 3; ++s) P.a[nxt + s] = *(const LDS_AS u32x4 *)(P.rd_base + (3 * nu + s) * 1024);
-}
-
-template <int U>
-__device__ __forceinline__ void pipe_dma(PipeX &P) {
-    if constexpr (U >= 4) glds_piece_off<(U - 4) * 1024>(P.lane16, P.cur_src, P.cur_dst);
-    else if constexpr (U <= 1) glds_piece_off<U * 1024>(P.lane16, P.cur_src_hi, P.cur_dst_hi);
-}
+#include "mlp_x3_pipe.hip.h"
 
 #define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
 #define XB_PIN() __builtin_amdgcn_sched_barrier(0)
