@@ -42,6 +42,9 @@ constexpr int kX3Ahead = NERF_X3_AHEAD; // operand prefetch distance in units (1
 
 #include "mlp_x3_pipe.hip.h"
 
+#ifndef NERF_X3_DIAG_DROP_W3
+#define NERF_X3_DIAG_DROP_W3 0
+#endif
 #ifndef NERF_X3_DIAG_MFMA_16X16
 #define NERF_X3_DIAG_MFMA_16X16 0 // timing/power experiment only (results are garbage): the same FLOPs as two 16x16x32 MFMAs
 #endif
@@ -131,7 +134,11 @@ __device__ __forceinline__ void k_step(f32x16 (&out)[8], const B3 &bc, const f32
         PrepState st;
         pipe_take<U>(P, a1, a2, a3);
         X3_PIN();
+#if NERF_X3_DIAG_DROP_W3 // accuracy / speed experiment only: five products, the weights' third part ignored
+        asm volatile("" ::"v"(a3));
+#else
         out[nt] = MFMA16(a3, b1, out[nt]);
+#endif
         X3_PIN();
         pipe_prefetch<U>(P);
         X3_PIN();
