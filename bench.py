@@ -212,8 +212,11 @@ def main():
         ms = 1e3 * (time.perf_counter() - t1) / 3
         extra_x3 = {"rays_per_s": args.width * args.height * args.ssaa * args.ssaa / (ms * 1e-3), "ms_per_step": ms,
                     "max_abs_diff_vs_f32_frame": float(diff.max().item()), "mean_abs_diff_vs_f32_frame": float(diff.mean().item()),
+                    "fraction_of_values_differing_by_more_than_5e-5": float((diff > 5e-5).float().mean().item()),
+                    "psnr_vs_f32_frame_db": float(-10.0 * torch.log10((diff.double() ** 2).mean().clamp_min(1e-30)).item()),
                     "note": "opt-in mlp_dtype bf16x3: every f32 product as the six significant bf16 x bf16 products of three-way splits, "
-                            "f32 accumulate; passes the f32 path's tolerances against the oracle (tests/test_gpu_parity.py)"}
+                            "f32 accumulate; passes the f32 path's tolerances against the oracle (tests/test_gpu_parity.py); the few values "
+                            "above 5e-5 are pixels where a coarse-density difference of 1e-5 relocates one fine sample (DESIGN 6, parity row)"}
         r.kernel_time_query(reset=True)
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev if not use_dist or dist.get_backend() == "nccl" else "cpu")
     if use_dist:
