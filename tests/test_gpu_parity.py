@@ -583,6 +583,41 @@ def test_bf16x3_render_matches_oracle_crop(renderer, native, samples):
     assert np.array_equal(sk, img)
 
 
+def test_random_weight_network_all_arithmetics(native, oracle, tmp_path):
+    """Nothing in the packers or kernels may depend on the lego weights: a network of the same architecture with random
+    (He-scaled, dense, no zero rows) weights, written in the reference's directory format, must pass the same gates --
+    f32 and bf16x3 against the oracle at the f32 tolerances, bf16 against the oracle's bf16 emulation."""
+    rng = np.random.default_rng(123)
+    shapes = [("dense0", 63, 256)] + [(f"dense{i}", 256, 256) for i in range(1, 5)] + [("dense5", 319, 256), ("dense6", 256, 256),
+              ("dense7", 256, 256), ("bottleneck", 256, 256), ("viewdirs", 283, 128), ("rgb", 128, 3), ("alpha", 256, 1)]
+    d = tmp_path / "rnd"
+    d.mkdir()
+    lines = []
+    for name, k, n in shapes:
+        w = (rng.normal(size=(k, n)) * np.sqrt(2.0 / k)).astype("<f4")
+        b = (rng.normal(size=(n,)) * 0.1).astype("<f4")
+        if name == "alpha":
+            b[:] = 0.7                                                   # keep a good share of the densities positive
+        w.tofile(d / f"{name}_kernel.bin"); b.tofile(d / f"{name}_bias.bin")
+        lines += [f"{name}_kernel {k} {n}", f"{name}_bias {n}"]
+    (d / "shapes.txt").write_text("\n".join(lines) + "\n")
+    n = 8192
+    pts = rng.uniform(-2.0, 2.0, size=(3, n)).astype(np.float32)
+    v = rng.normal(size=(n, 3)); dirs = (v / np.linalg.norm(v, axis=1, keepdims=True)).astype(np.float32)
+    onet = oracle.Net(str(d))
+    ergb, esg = onet.forward_batch(pts, dirs)
+    assert (esg > 0).mean() > 0.05 and np.isfinite(esg).all()           # a live network, not all-dead ReLUs
+    with native.Renderer(0) as r:
+        net = native.load_network_from_dir(r, 0, d)
+        for dt in ("f32", "bf16x3"):
+            rgb, sg = net.forward_batch(pts, dirs, dtype=dt)
+            _close_mlp(rgb, sg, ergb, esg)
+        brgb, bsg = net.forward_batch(pts, dirs, dtype="bf16")
+        e2rgb, e2sg = onet.forward_batch_bf16(pts, dirs)
+        ds = np.abs(bsg - e2sg) / (1 + np.abs(e2sg)); dr = np.abs(brgb - e2rgb)
+        assert np.quantile(ds, 0.99) <= 1e-3 and ds.max() <= 0.1 and np.quantile(dr, 0.99) <= 1e-3 and dr.max() <= 0.05
+
+
 def _forward_fp64(scene_sub, pts, dirs):
     """The network (src/network.rs:197-237) in float64 numpy: the exact-arithmetic yardstick for both f32 paths."""
     d = os.path.join(SCENE, scene_sub)
