@@ -480,6 +480,12 @@ def test_odd_sample_counts_and_large_batches(renderer, native, oracle, oracle_ne
     img2 = native.render_image(renderer.coarse, renderer.fine, cam2, 5, seed=9, crop=crop)
     ref2 = oracle.render_image(*oracle_nets, ocam, oracle.make_opts(2, 5, crop=crop, seed=9))
     _gate1(img2, ref2)
+    # the same ragged shapes through the other two arithmetics: bf16x3 at the f32 gate, bf16 at PSNR level
+    _gate1(native.render_image(renderer.coarse, renderer.fine, cam, 50, seed=9, crop=crop, dtype="bf16x3"), ref)
+    _gate1(native.render_image(renderer.coarse, renderer.fine, cam3, 5, seed=9, crop=crop, dtype="bf16x3"), ref3)
+    _gate1(native.render_image(renderer.coarse, renderer.fine, cam2, 5, seed=9, crop=crop, dtype="bf16x3"), ref2)
+    assert psnr(native.render_image(renderer.coarse, renderer.fine, cam, 50, seed=9, crop=crop, dtype="bf16"), ref) >= 30.0
+    assert psnr(native.render_image(renderer.coarse, renderer.fine, cam3, 5, seed=9, crop=crop, dtype="bf16"), ref3) >= 30.0
     # 3 M points through forward_batch: every 1000th point against the fixture values it repeats
     g = golden("forward_batch_4096.npz")
     reps = 733
