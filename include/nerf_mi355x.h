@@ -163,6 +163,8 @@ int nerf_camera_from_pose(const float c2w[12], float ref_h, float ref_w, float f
 /* save_ppm (src/lib.rs:567-580): P6, (clamp(v,0,1)*255+0.5) as u8 */
 int nerf_save_ppm(const char *path, int width, int height, const float *rgb);
 void nerf_quantize_rgb8(const float *rgb, size_t n_pixels, uint8_t *out);
+/* pixels_to_rgba (src/lib.rs:582-592; the reference's wasm canvas path): the same quantisation, alpha = 255 */
+void nerf_quantize_rgba8(const float *rgb, size_t n_pixels, uint8_t *out /* 4 n_pixels */);
 
 /* ---- stage entry points (device execution, host buffers): the individual functions of render_block, exposed so
  * that a host that owns ray setup can call them and so that each stage has its own parity test ------------- */

@@ -71,6 +71,7 @@ PROTOTYPES = {
                                           C.POINTER(CCamera)]),
     "nerf_save_ppm": (C.c_int, [C.c_char_p, C.c_int, C.c_int, f32p]),
     "nerf_quantize_rgb8": (None, [f32p, C.c_size_t, C.POINTER(C.c_uint8)]),
+    "nerf_quantize_rgba8": (None, [f32p, C.c_size_t, C.POINTER(C.c_uint8)]),
     "nerf_stage_ray_dirs": (C.c_int, [C.c_void_p, C.POINTER(CCamera), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, f32p]),
     "nerf_stage_stratified": (C.c_int, [C.c_void_p, C.POINTER(CCamera), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                         C.c_uint64, f32p]),

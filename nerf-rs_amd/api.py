@@ -254,6 +254,14 @@ def quantize_rgb8(pixels):
     return out
 
 
+def quantize_rgba8(pixels):
+    """pixels_to_rgba (src/lib.rs:582-592): (..., 3) f32 -> (..., 4) u8 with alpha 255."""
+    a = _f32(pixels)
+    out = np.empty(a.shape[:-1] + (4,), np.uint8)
+    _lib.load_library().nerf_quantize_rgba8(_p(a), a.size // 3, out.ctypes.data_as(C.POINTER(C.c_uint8)))
+    return out
+
+
 def save_ppm(path, width, height, pixels):
     """save_ppm (src/lib.rs:567-580); pixels: (height, width, 3) or (height*width, 3)."""
     a = _f32(pixels)

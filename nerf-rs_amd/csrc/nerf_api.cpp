@@ -828,6 +828,12 @@ int nerf_save_ppm(const char *path, int width, int height, const float *rgb) {
 
 void nerf_quantize_rgb8(const float *rgb, size_t n_pixels, uint8_t *out) { quantize_rgb8(rgb, n_pixels, out); }
 
+void nerf_quantize_rgba8(const float *rgb, size_t n_pixels, uint8_t *out) {
+    std::vector<uint8_t> tmp(3 * n_pixels);
+    quantize_rgb8(rgb, n_pixels, tmp.data());
+    for (size_t i = 0; i < n_pixels; ++i) { out[4 * i] = tmp[3 * i]; out[4 * i + 1] = tmp[3 * i + 1]; out[4 * i + 2] = tmp[3 * i + 2]; out[4 * i + 3] = 255; }
+}
+
 // ---- stage entry points ------------------------------------------------------------------------------------
 static int stage_rect(nerf_ctx *c, const nerf_camera *cam, int x0, int y0, int w, int h, RayGenArgs &g) {
     int rc;

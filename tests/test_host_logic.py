@@ -120,6 +120,8 @@ def test_save_ppm_matches_oracle(native, oracle, tmp_path):
     img = rng.uniform(-0.2, 1.2, size=(5, 7, 3)).astype(np.float32)
     img[0, 0] = [np.nan, 0.5, 1.0]
     assert np.array_equal(native.quantize_rgb8(img), oracle.quantize_rgb8(img))
+    rgba = native.quantize_rgba8(img)                                              # pixels_to_rgba, src/lib.rs:582-592
+    assert rgba.shape == img.shape[:-1] + (4,) and np.array_equal(rgba[..., :3], native.quantize_rgb8(img)) and (rgba[..., 3] == 255).all()
     a, b = tmp_path / "a.ppm", tmp_path / "b.ppm"
     native.save_ppm(a, 7, 5, img); oracle.save_ppm(b, img)
     assert a.read_bytes() == b.read_bytes() and a.read_bytes().startswith(b"P6\n7 5\n255\n")
