@@ -88,6 +88,7 @@ extern "C" {
                                    hwf: *const f32, width: c_int, height: c_int, out: *mut nerf_camera) -> c_int;
     pub fn nerf_save_ppm(path: *const c_char, width: c_int, height: c_int, rgb: *const f32) -> c_int;
     pub fn nerf_quantize_rgb8(rgb: *const f32, n_pixels: usize, out: *mut u8);
+    pub fn nerf_quantize_rgba8(rgb: *const f32, n_pixels: usize, out: *mut u8);
     pub fn nerf_stage_ray_dirs(ctx: *mut nerf_ctx, cam: *const nerf_camera, x0: c_int, y0: c_int, w: c_int, h: c_int,
                                normalize: c_int, dirs_out: *mut f32) -> c_int;
     pub fn nerf_stage_stratified(ctx: *mut nerf_ctx, cam: *const nerf_camera, x0: c_int, y0: c_int, w: c_int, h: c_int,
