@@ -166,8 +166,32 @@ __global__ __launch_bounds__(256) void k_resample(ResampleArgs a) {
 
     // merged.sort_by(partial_cmp) (:419).  Only the sorted VALUES leave this kernel and equal floats are interchangeable, so any
     // correct sort reproduces the reference's stable sort bit for bit: a bitonic network over the next power of two (pad =
-    // +inf), two compare-exchanges per lane and step, in LDS (36 steps for 192 -> 256 instead of 192 compares per element).
+    // +inf).  Up to 256 elements (the shipped 64 + 128 configuration) it runs in registers: a lane owns four consecutive
+    // elements, compare-exchange distances 1 and 2 stay inside the lane, larger ones exchange whole lanes by __shfl_xor --
+    // no LDS traffic, no bank conflicts, no wave barriers.  Wider sorts fall back to the same network in LDS.
     const int P = a.sort_pow2;
+    if (P <= 256) {
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const int i = 4 * lane + e; v[e] = i < M ? mg[i] : __builtin_inff(); }
+        auto cx = [](float &x, float &y, bool up) { const float lo = fminf(x, y), hi = fmaxf(x, y); x = up ? lo : hi; y = up ? hi : lo; };
+        for (int k = 2; k <= 256; k <<= 1) {
+            if (k > P) break;                                    // elements beyond P are +inf padding in sorted position
+            for (int j = k >> 1; j >= 4; j >>= 1) {              // partner element 4 (lane ^ (j / 4)) + e
+                const bool up = ((4 * lane) & k) == 0, lower = ((4 * lane) & j) == 0;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float o = __shfl_xor(v[e], j >> 2, 64);
+                    v[e] = (lower == up) ? fminf(v[e], o) : fmaxf(v[e], o);
+                }
+            }
+            if (k >= 4) { const bool up = ((4 * lane) & k) == 0; cx(v[0], v[2], up); cx(v[1], v[3], up); cx(v[0], v[1], up); cx(v[2], v[3], up); }
+            else        { cx(v[0], v[1], true); cx(v[2], v[3], false); }  // k = 2: direction = bit 1 of the element index
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const int i = 4 * lane + e; if (i < M) a.t_fine[(size_t)ray * M + i] = v[e]; }
+        return;
+    }
     for (int e = M + lane; e < P; e += 64) mg[e] = __builtin_inff();
     wave_sync();
     for (int k = 2; k <= P; k <<= 1) {
