@@ -250,10 +250,9 @@ def main():
                        "skip_empty": bool(args.skip_empty), "colour_head_skipped_samples_per_frame": skipped_per_launch,
                        "whole_job_fraction_of_mfma_roofline": mfma_per_flop * value * flop_ray / (world * peak * 1e12)},  # per-GPU average
             "roofline": {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
-                         "frac": ach / peak, "traffic": pmc_traffic_bytes(("void nerf_mlp_kernel_bf16<true" if os.environ.get("NERF_BF16_KERNEL") == "v1"
-                                                        else "void nerf_mlp_kernel_bf16v2<true") if bf16 else
+                         "frac": ach / peak, "traffic": pmc_traffic_bytes("void nerf_mlp_kernel_bf16v2<true" if bf16 else
                                                        "void nerf_mlp_kernel_bf16x3<true" if x3 else "void nerf_mlp_kernel<true"),
-                         "kernel": (("nerf_mlp_kernel_bf16" if os.environ.get("NERF_BF16_KERNEL") == "v1" else "nerf_mlp_kernel_bf16v2") if bf16
+                         "kernel": ("nerf_mlp_kernel_bf16v2" if bf16
                                     else "nerf_mlp_kernel_bf16x3" if x3 else "nerf_mlp_kernel") + "<FULL=true, MODE_RAYS> (fine network)",
                          "launches": n_dom, "avg_launch_ms": ms_dom / max(n_dom, 1),
                          "points_per_launch": pts_dom // max(n_dom, 1), "flop_per_point": N.FLOP_PER_POINT_FULL},

@@ -66,8 +66,6 @@ typedef struct {
     uint64_t seed;        /* counter-RNG seed (reference: unseeded thread_rng, src/lib.rs:375,407) */
     int32_t mlp_dtype;    /* ext: NERF_MLP_F32 (0, default: exact-f32 MFMA, the parity path) or NERF_MLP_BF16 (1: bf16
                            * operands / f32 accumulate on the bf16 matrix cores -- BASELINE config C5; PSNR-level parity).
-                           * Environment, read by nerf_create: NERF_BF16_KERNEL=v1 selects the first of the two bf16 kernel
-                           * designs (A/B runs; same arithmetic).
                            * NERF_MLP_BF16X3 (2, opt-in): f32-accurate arithmetic on the bf16 matrix cores -- every weight and
                            * activation is split into three bf16 parts (exact to 2^-27) and a product is the sum of the six
                            * significant bf16 x bf16 products, accumulated in f32; meets the f32 path's tolerances */

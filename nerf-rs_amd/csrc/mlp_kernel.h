@@ -29,15 +29,9 @@ struct MlpArgs {
 hipError_t nerf_mlp_init();
 // full=false evaluates dense0..7 + alpha only (sigma); n_blocks = persistent workgroups (<= #CUs).
 hipError_t nerf_mlp_launch(const MlpArgs &a, bool full, int n_blocks, hipStream_t stream);
-// bf16-operand variant (mlp_kernel_bf16.hip): a.wstream is the bf16 stream of pack_network_bf16
-hipError_t nerf_mlp_bf16_init();
-hipError_t nerf_mlp_bf16_launch(const MlpArgs &a, bool full, int n_blocks, hipStream_t stream);
-// second bf16 design (mlp_kernel_bf16v2.hip): a.wstream is the output-tile-major stream (mlp_layout.h kChunks*Bf16V2)
+// bf16-operand variant (mlp_kernel_bf16v2.hip): a.wstream is the output-tile-major stream (mlp_layout.h kChunks*Bf16V2)
 hipError_t nerf_mlp_bf16v2_init();
 hipError_t nerf_mlp_bf16v2_launch(const MlpArgs &a, bool full, int n_blocks, hipStream_t stream);
 // f32 by three-way bf16 split (mlp_kernel_bf16x3.hip): a.wstream is the three-part stream (mlp_layout.h kChunks*X3)
 hipError_t nerf_mlp_bf16x3_init();
 hipError_t nerf_mlp_bf16x3_launch(const MlpArgs &a, bool full, int n_blocks, hipStream_t stream);
-// the same arithmetic on v_mfma_f32_16x16x32_bf16 (mlp_kernel_bf16x3b.hip): its own stream permutation, small params in feature order
-hipError_t nerf_mlp_bf16x3b_init();
-hipError_t nerf_mlp_bf16x3b_launch(const MlpArgs &a, bool full, int n_blocks, hipStream_t stream);

@@ -29,11 +29,8 @@ thread_local std::string g_err; // context-free calls
 
 struct DevNet {
     float *wstream = nullptr, *small = nullptr;
-    uint16_t *wstream_bf16 = nullptr; // built from the same tensors at load time (mlp_kernel_bf16.hip)
-    uint16_t *wstream_bf16v2 = nullptr; // the same pieces in output-tile-major order (mlp_kernel_bf16v2.hip)
+    uint16_t *wstream_bf16v2 = nullptr; // bf16 pieces in output-tile-major order (mlp_kernel_bf16v2.hip)
     uint16_t *wstream_x3 = nullptr;     // three bf16 parts per weight (mlp_kernel_bf16x3.hip)
-    uint16_t *wstream_x3b = nullptr;    // the same for the 16x16x32 tiling (mlp_kernel_bf16x3b.hip)
-    float *small16 = nullptr;           // small parameters in natural feature order (mlp_kernel_bf16x3b.hip)
     bool loaded = false;
 };
 
@@ -48,8 +45,6 @@ struct EvPair {
 struct nerf_ctx {
     int device = 0;
     int n_cus = 0;
-    bool bf16_v1 = false; // NERF_BF16_KERNEL=v1 selects the first bf16 design (mlp_kernel_bf16.hip) for A/B runs
-    bool x3b = false;     // NERF_X3_KERNEL=b selects the 16x16x32 tiling of the bf16x3 arithmetic for A/B runs
     std::string arch;
     std::string err;
     hipStream_t stream = nullptr; // used by the host-pointer entry points
@@ -147,15 +142,14 @@ int upload_packed(nerf_ctx *c, int which, const std::vector<float> &ws, const st
 
 // weight stream + launcher of the selected arithmetic
 static bool valid_dtype(int d) { return d == NERF_MLP_F32 || d == NERF_MLP_BF16 || d == NERF_MLP_BF16X3; }
-static const float *stream_of(const nerf_ctx *c, const DevNet &n, int dtype) {
-    if (dtype == NERF_MLP_BF16X3) return (const float *)(c->x3b ? n.wstream_x3b : n.wstream_x3);
-    return dtype == NERF_MLP_F32 ? n.wstream : (const float *)(c->bf16_v1 ? n.wstream_bf16 : n.wstream_bf16v2);
+static const float *stream_of(const DevNet &n, int dtype) {
+    if (dtype == NERF_MLP_BF16X3) return (const float *)n.wstream_x3;
+    return dtype == NERF_MLP_F32 ? n.wstream : (const float *)n.wstream_bf16v2;
 }
-static const float *small_of(const nerf_ctx *c, const DevNet &n, int dtype) { return (dtype == NERF_MLP_BF16X3 && c->x3b) ? n.small16 : n.small; }
 static hipError_t launch_mlp(const nerf_ctx *c, int dtype, const MlpArgs &a, bool full, hipStream_t st) {
     if (dtype == NERF_MLP_F32) return nerf_mlp_launch(a, full, c->n_cus, st);
-    if (dtype == NERF_MLP_BF16X3) return c->x3b ? nerf_mlp_bf16x3b_launch(a, full, c->n_cus, st) : nerf_mlp_bf16x3_launch(a, full, c->n_cus, st);
-    return c->bf16_v1 ? nerf_mlp_bf16_launch(a, full, c->n_cus, st) : nerf_mlp_bf16v2_launch(a, full, c->n_cus, st);
+    if (dtype == NERF_MLP_BF16X3) return nerf_mlp_bf16x3_launch(a, full, c->n_cus, st);
+    return nerf_mlp_bf16v2_launch(a, full, c->n_cus, st);
 }
 
 // v1 stream -> v2 stream: the 1-KiB pieces are identical (lane l, element j = W[row(tile, 8 ks + j, l >> 5)][32 nt + (l & 31)]);
@@ -181,58 +175,6 @@ static void bf16_v2_from_v1(const std::vector<uint16_t> &v1, std::vector<uint16_
     v2.resize((size_t)kChunksFullBf16V2 * kChunkBytesBf16V2 / 2, (uint16_t)0);
 }
 
-// bf16x3 stream of the 16x16x32 tiling: a permutation of the same piece array.  Unit (input tile T, output tile nt, half ob):
-// lane (i = l & 15, g = l >> 4), element j is row 16 (j >> 2) + 4 g + (j & 3) of tile T, column 32 nt + 16 ob + i; in the
-// 32x32 layouts that row is register r = 4 (row >> 3) + (row & 3) of lane-half h = (row >> 2) & 1.
-static void x3b_stream_from_v1order(const std::vector<float> &v1f, std::vector<uint16_t> &ws) {
-    using namespace nerfmlp;
-    ws.clear();
-    ws.reserve((size_t)kChunksFullX3 * kChunkBytesX3 / 2);
-    size_t base = 0; // v1 pieces
-    std::vector<float> piece(512);
-    auto layer = [&](int tiles, int NT) {
-        for (int T = 0; T < tiles; ++T)
-            for (int nt = 0; nt < NT; ++nt)
-                for (int ob = 0; ob < 2; ++ob) {
-                    for (int l = 0; l < 64; ++l)
-                        for (int j = 0; j < 8; ++j) {
-                            const int i = l & 15, g = l >> 4;
-                            const int row = 16 * (j >> 2) + 4 * g + (j & 3);
-                            const int r = 4 * (row >> 3) + (row & 3), h = (row >> 2) & 1, ks = r >> 3, j1 = r & 7;
-                            const size_t pc = base + (size_t)(T * 2 + ks) * NT + nt;
-                            piece[l * 8 + j] = v1f[pc * 512 + (size_t)(32 * h + 16 * ob + i) * 8 + j1];
-                        }
-                    for (int s3 = 0; s3 < 3; ++s3)
-                        for (int e = 0; e < 512; ++e) {
-                            uint16_t parts[3];
-                            split_bf16x3(piece[e], parts);
-                            ws.push_back(parts[s3]);
-                        }
-                }
-        base += (size_t)tiles * 2 * NT;
-    };
-    layer(2, 8);
-    for (int i = 0; i < 4; ++i) layer(8, 8);
-    layer(10, 8);
-    for (int i = 0; i < 3; ++i) layer(8, 8);
-    layer(9, 4);
-}
-
-// small parameters in natural feature order from the packed block (mlp_layout.h): feature 32 t + rel sits at register
-// r = 4 (rel >> 3) + (rel & 3) of lane-half h = (rel >> 2) & 1 of tile t
-static void small16_from_small(const std::vector<float> &sm, std::vector<float> &out) {
-    using namespace nerfmlp;
-    out.assign(kSmallFloats, 0.0f);
-    auto rh = [](int rel, int &r, int &h) { r = 4 * (rel >> 3) + (rel & 3); h = (rel >> 2) & 1; };
-    for (int L = 0; L < 9; ++L)
-        for (int f = 0; f < 256; ++f) { int r, h; rh(f & 31, r, h); out[kBiasOff + L * 256 + f] = sm[kBiasOff + L * 256 + ((f >> 5) * 2 + h) * 16 + r]; }
-    for (int f = 0; f < 128; ++f) { int r, h; rh(f & 31, r, h); out[kBiasViewOff + f] = sm[kBiasViewOff + ((f >> 5) * 2 + h) * 16 + r]; }
-    for (int f = 0; f < 256; ++f) { int r, h; rh(f & 31, r, h); out[kAlphaWOff + f] = sm[kAlphaWOff + h * 128 + (f >> 5) * 16 + r]; }
-    for (int c = 0; c < 3; ++c)
-        for (int f = 0; f < 128; ++f) { int r, h; rh(f & 31, r, h); out[kRgbWOff + c * 128 + f] = sm[kRgbWOff + (h * 3 + c) * 64 + (f >> 5) * 16 + r]; }
-    for (int k = 0; k < 4; ++k) out[kMiscOff + k] = sm[kMiscOff + k];
-}
-
 // All bf16-family streams come from one f32 array in the first bf16 design's piece order (host_util.h).
 int upload_bf16_family(nerf_ctx *c, int which, const std::vector<float> &v1f) {
     if (v1f.size() != (size_t)nerfmlp::kPiecesV1 * 512) return fail(c, NERF_ERR_SHAPE, "internal: bf16 piece array has the wrong size");
@@ -242,19 +184,10 @@ int upload_bf16_family(nerf_ctx *c, int which, const std::vector<float> &v1f) {
     bf16_v2_from_v1(wb, v2);
     x3_stream_from_v1order(v1f, x3);
     if (x3.size() != (size_t)nerfmlp::kChunksFullX3 * nerfmlp::kChunkBytesX3 / 2) return fail(c, NERF_ERR_SHAPE, "internal: bf16x3 stream size");
-    if (!d.wstream_bf16) HIP_TRY(c, hipMalloc((void **)&d.wstream_bf16, wb.size() * sizeof(uint16_t)));
-    HIP_TRY(c, hipMemcpy(d.wstream_bf16, wb.data(), wb.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
     if (!d.wstream_bf16v2) HIP_TRY(c, hipMalloc((void **)&d.wstream_bf16v2, v2.size() * sizeof(uint16_t)));
     HIP_TRY(c, hipMemcpy(d.wstream_bf16v2, v2.data(), v2.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
     if (!d.wstream_x3) HIP_TRY(c, hipMalloc((void **)&d.wstream_x3, x3.size() * sizeof(uint16_t)));
     HIP_TRY(c, hipMemcpy(d.wstream_x3, x3.data(), x3.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
-    if (c->x3b) {
-        std::vector<uint16_t> xb;
-        x3b_stream_from_v1order(v1f, xb);
-        if (xb.size() != x3.size()) return fail(c, NERF_ERR_SHAPE, "internal: bf16x3b stream size");
-        if (!d.wstream_x3b) HIP_TRY(c, hipMalloc((void **)&d.wstream_x3b, xb.size() * sizeof(uint16_t)));
-        HIP_TRY(c, hipMemcpy(d.wstream_x3b, xb.data(), xb.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
-    }
     return NERF_OK;
 }
 
@@ -303,12 +236,6 @@ int upload_packed(nerf_ctx *c, int which, const std::vector<float> &ws, const st
     if (!d.small) HIP_TRY(c, hipMalloc((void **)&d.small, sm.size() * sizeof(float)));
     HIP_TRY(c, hipMemcpy(d.wstream, ws.data(), ws.size() * sizeof(float), hipMemcpyHostToDevice));
     HIP_TRY(c, hipMemcpy(d.small, sm.data(), sm.size() * sizeof(float), hipMemcpyHostToDevice));
-    if (c->x3b) {
-        std::vector<float> s16;
-        small16_from_small(sm, s16);
-        if (!d.small16) HIP_TRY(c, hipMalloc((void **)&d.small16, s16.size() * sizeof(float)));
-        HIP_TRY(c, hipMemcpy(d.small16, s16.data(), s16.size() * sizeof(float), hipMemcpyHostToDevice));
-    }
     d.loaded = true;
     return NERF_OK;
 }
@@ -358,7 +285,6 @@ int render_device(nerf_ctx *c, const nerf_camera *cam, const nerf_render_opts *o
     for (int r : o->reserved) if (r != 0) return fail(c, NERF_ERR_INVALID, "reserved option fields must be 0");
     if (!valid_dtype(o->mlp_dtype)) return fail(c, NERF_ERR_INVALID, "mlp_dtype must be NERF_MLP_F32, NERF_MLP_BF16 or NERF_MLP_BF16X3");
     const int dtype = o->mlp_dtype;
-    const bool bf16 = dtype == NERF_MLP_BF16;
     if (o->skip_empty != 0 && o->skip_empty != 1) return fail(c, NERF_ERR_INVALID, "skip_empty must be 0 or 1");
     if (!c->net[NERF_NET_COARSE].loaded) return fail(c, NERF_ERR_STATE, "coarse network not loaded");
     if (!o->coarse_only && !c->net[NERF_NET_FINE].loaded) return fail(c, NERF_ERR_STATE, "fine network not loaded");
@@ -407,7 +333,7 @@ int render_device(nerf_ctx *c, const nerf_camera *cam, const nerf_render_opts *o
         a.ray_dirs = c->d_dirs;
         a.origin[0] = cam->pos[0]; a.origin[1] = cam->pos[1]; a.origin[2] = cam->pos[2];
         // coarse network: sigma only unless its colours are composited (reference discards them, src/lib.rs:404)
-        a.wstream = stream_of(c, NC, dtype); a.small_params = small_of(c, NC, dtype);
+        a.wstream = stream_of(NC, dtype); a.small_params = NC.small;
         a.n_points = n_rays * nc; a.samples_per_ray = nc; a.t = c->d_tc;
         a.sigma_out = c->d_sc; a.rgb_out = c->d_rgbc;
         a.skip_empty = o->skip_empty; a.skip_counter = o->skip_empty ? c->d_skip : nullptr; // only full kernels look at it
@@ -437,11 +363,11 @@ int render_device(nerf_ctx *c, const nerf_camera *cam, const nerf_render_opts *o
             t.done(c->last_render);
             t_fine = c->d_tf;
         }
-        a.wstream = stream_of(c, NF, dtype); a.small_params = small_of(c, NF, dtype);
+        a.wstream = stream_of(NF, dtype); a.small_params = NF.small;
         a.n_points = n_rays * M; a.samples_per_ray = M; a.t = t_fine;
         a.sigma_out = c->d_sf; a.rgb_out = c->d_rgbf;
         a.clock_out = c->d_clock; // NULL unless NERF_DEBUG_CLOCK=1
-        c->clock_valid = c->d_clock != nullptr && !(bf16 && c->bf16_v1); // the first bf16 design writes no stamps
+        c->clock_valid = c->d_clock != nullptr;
         {
             Timed t(c, st, 1, (uint64_t)a.n_points, timing);
             HIP_TRY(c, launch_mlp(c, dtype, a, true, st));
@@ -527,14 +453,10 @@ int nerf_create(int device_id, nerf_ctx **out) {
     if (const char *env = getenv("NERF_DEBUG_CLOCK")) {
         if (atoi(env) > 0 && hipMalloc((void **)&c->d_clock, (size_t)c->n_cus * 2 * sizeof(unsigned long long)) != hipSuccess) c->d_clock = nullptr;
     }
-    if (const char *env = getenv("NERF_BF16_KERNEL")) c->bf16_v1 = std::string(env) == "v1";
-    if (const char *env = getenv("NERF_X3_KERNEL")) c->x3b = std::string(env) == "b";
     if (hipMalloc((void **)&c->d_skip, sizeof(unsigned long long)) != hipSuccess) c->d_skip = nullptr;
     hipError_t e1 = nerf_mlp_init();
-    if (e1 == hipSuccess) e1 = nerf_mlp_bf16_init();
     if (e1 == hipSuccess) e1 = nerf_mlp_bf16v2_init();
     if (e1 == hipSuccess) e1 = nerf_mlp_bf16x3_init();
-    if (e1 == hipSuccess) e1 = nerf_mlp_bf16x3b_init();
     hipError_t e2 = e1 == hipSuccess ? sampling_init() : e1;
     hipError_t e3 = e2 == hipSuccess ? hipStreamCreate(&c->stream) : e2;
     if (e3 != hipSuccess) {
@@ -550,7 +472,7 @@ void nerf_destroy(nerf_ctx *c) {
     if (!c) return;
     DeviceGuard dg(c->device);
     (void)hipDeviceSynchronize();
-    for (auto &n : c->net) { if (n.wstream) (void)hipFree(n.wstream); if (n.small) (void)hipFree(n.small); if (n.wstream_bf16) (void)hipFree(n.wstream_bf16); if (n.wstream_bf16v2) (void)hipFree(n.wstream_bf16v2); if (n.wstream_x3) (void)hipFree(n.wstream_x3); if (n.wstream_x3b) (void)hipFree(n.wstream_x3b); if (n.small16) (void)hipFree(n.small16); }
+    for (auto &n : c->net) { if (n.wstream) (void)hipFree(n.wstream); if (n.small) (void)hipFree(n.small); if (n.wstream_bf16v2) (void)hipFree(n.wstream_bf16v2); if (n.wstream_x3) (void)hipFree(n.wstream_x3); }
     float *ptrs[] = {c->d_dirs, c->d_tc, c->d_sc, c->d_rgbc, c->d_tf, c->d_sf, c->d_rgbf, c->d_rayfb, c->d_out};
     for (float *p : ptrs) if (p) (void)hipFree(p);
     if (c->d_scratch) (void)hipFree(c->d_scratch);
@@ -716,7 +638,7 @@ static int forward_device(nerf_ctx *c, int which, int dtype, const float *d_pts,
     MlpArgs a{};
     a.mode = MLP_MODE_POINTS;
     if (!valid_dtype(dtype)) return fail(c, NERF_ERR_INVALID, "mlp_dtype must be NERF_MLP_F32, NERF_MLP_BF16 or NERF_MLP_BF16X3");
-    a.wstream = stream_of(c, c->net[which], dtype); a.small_params = small_of(c, c->net[which], dtype);
+    a.wstream = stream_of(c->net[which], dtype); a.small_params = c->net[which].small;
     a.n_points = (int)n; a.pts_soa = d_pts; a.dirs_aos = d_dirs; a.sigma_out = d_sigma; a.rgb_out = d_rgb;
     HIP_TRY(c, launch_mlp(c, dtype, a, true, (hipStream_t)stream));
     return NERF_OK;
