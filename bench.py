@@ -3,11 +3,14 @@
 
 A "step" is one full frame through the hot path (ray gen -> stratified -> coarse MLP -> resample -> fine MLP ->
 composite [-> RCCL all-gather of the row bands when N > 1]) with weights and all intermediates resident in HBM.
-    python bench.py --gpus 1 --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (N > 1: this process starts the N ranks itself)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
-Rank 0 prints ONE JSON line.  `roofline` is the fine-network MLP kernel (the dominant launch) measured with HIP
-events on the render stream inside the timed region; `cpu_baseline` is the CPU oracle (a port of the reference's
-algorithm, reference loop order) timed on this host's cores on a bounded sample of the same workload.
+Both launch forms run the same rank code: one process per GPU, torch.distributed over RCCL ("nccl"), row bands + ONE
+all-gather of the framebuffer.  Rank 0 prints ONE JSON line.  `roofline` is the fine-network MLP kernel (the dominant
+launch) measured with HIP events on the render stream inside the timed region; `cpu_baseline` is the CPU oracle (a
+port of the reference's algorithm) timed on this host's cores in the REFERENCE'S OWN LOOP ORDER (forward_fallback,
+src/network.rs:124-147) on one 8x8 block per thread at the reference CLI's 256x256 geometry; the oracle's cache-blocked
+nest (bit-identical results) is reported beside it as `blocked_rays_per_s`.
 """
 import argparse
 import json
@@ -34,8 +37,8 @@ def pmc_traffic_bytes(kernel_prefix="void nerf_mlp_kernel<true"):
         for row in csv.DictReader(open(f)):
             if row["kernel"].startswith(kernel_prefix) and float(row.get("FETCH_SIZE", 0) or 0) > 0:
                 n = max(int(row["dispatches"]), 1)
-                return (2.0 * float(row["FETCH_SIZE"]) + float(row.get("WRITE_SIZE", 0) or 0)) * 1024.0 / n
-    return None
+                return (2.0 * float(row["FETCH_SIZE"]) + float(row.get("WRITE_SIZE", 0) or 0)) * 1024.0 / n, os.path.relpath(f, ROOT)
+    return None, None
 
 
 def host_cores():
@@ -51,39 +54,85 @@ def host_cores():
     return max(1, min(n, 32))
 
 
-def cpu_baseline(width, height, n_coarse, n_fine, seed, naive_too=False):
+def cpu_baseline(width, height, n_coarse, n_fine, seed, reference_order=True):
     """The CPU oracle (kind "port": a C restatement of the reference's algorithm, oracle/nerf_oracle.c) on this host's
-    cores, on a bounded crop of the same frame.  Default: the oracle's cache-blocked loop nest (bit-identical results
-    to the reference's nest, ~30-300x faster).  --cpu-naive additionally times forward_fallback's own loop order
-    (src/network.rs:134-143) on one 8x2-ray task per thread; measured on the round-1 GPU box (16 threads): 9.07 rays/s
-    with 8x8 blocks (113 s), 2.27 rays/s with 8x2 strips (113 s) -- too slow for a default run."""
+    cores.  `value` = the reference's own loop order (forward_fallback: k-outer / batch-middle / out-inner with separate
+    multiply and add, src/network.rs:134-143) on ONE 8x8 block (the reference's rayon task, src/lib.rs:491,533-550) per
+    thread, at the reference CLI's 256x256 geometry (src/lib.rs:657-658), same sample counts and seed: a fixed amount of
+    work per thread, ~2 min on the round-1 GPU box.  `blocked_rays_per_s` = the oracle's cache-blocked nest (bit-identical
+    results, ~400x faster) on a crop of the benchmark frame itself."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle_py as O
     scene = os.path.join(ROOT, "lego_rust")
     S = O.load_samples(os.path.join(scene, "tf_reference_samples.json"))
     co, fi = O.Net(os.path.join(scene, "coarse")), O.Net(os.path.join(scene, "fine"))
-    cam = O.camera_from_samples(S, width, height)
     cores = host_cores()
+    # (1) cache-blocked nest on a crop of the benchmark frame
+    cam = O.camera_from_samples(S, width, height)
     side = 8 * max(4, int(round((cores * 48) ** 0.5)))  # ~3000 rays (48 8x8 blocks) per thread: ~15 s on the GPU box
     side = min(side, (min(width, height) // 8) * 8)
     crop = ((width - side) // 2, (height - side) // 2, side, side)
-    n_rays = side * side
     t0 = time.time()
     O.render_image(co, fi, cam, O.make_opts(n_coarse, n_fine, crop=crop, seed=seed, naive=False, threads=cores))
+    dt_blocked = time.time() - t0
+    blocked = side * side / dt_blocked
+    blocked_note = (f"{side}x{side} crop at ({crop[0]},{crop[1]}) of the {width}x{height} frame in 8x8 blocks over {cores} threads, "
+                    f"cache-blocked loop nest (bit-identical to the reference's), {dt_blocked:.1f} s")
+    if not reference_order:
+        return {"value": blocked, "unit": "rays/s", "cores": cores, "kind": "port, cache-blocked loop nest (NOT the reference loop order)",
+                "sample": blocked_note + "; baseline, not target", "reference_loop_order_rays_per_s": None, "blocked_rays_per_s": blocked}
+    # (2) the reference's loop order: one 8x8 block per thread, centred in the 256x256 frame of the reference's CLI
+    cam256 = O.camera_from_samples(S, 256, 256)
+    bh = max(d for d in range(1, int(cores ** 0.5) + 1) if cores % d == 0)
+    bw = cores // bh
+    c2 = (max(0, 128 - 4 * bw) // 8 * 8, max(0, 128 - 4 * bh) // 8 * 8, min(8 * bw, 256), min(8 * bh, 256))
+    n_rays = c2[2] * c2[3]
+    t0 = time.time()
+    O.render_image(co, fi, cam256, O.make_opts(n_coarse, n_fine, crop=c2, seed=seed, naive=True, threads=cores))
     dt = time.time() - t0
-    out = {"value": n_rays / dt, "unit": "rays/s", "cores": cores, "kind": "port",
-           "sample": f"{side}x{side} crop at ({crop[0]},{crop[1]}) of the {width}x{height} frame = {n_rays} rays in 8x8 blocks "
-                     f"(the reference's rayon task, src/lib.rs:491,533) over {cores} threads, {n_coarse}+{n_fine} samples, "
-                     f"cache-blocked loop nest (bit-identical to the reference's), {dt:.1f} s; baseline, not target",
-           "reference_loop_order_rays_per_s": None}
-    if naive_too:
-        bh = max(d for d in range(1, int(cores ** 0.5) + 1) if cores % d == 0)
-        bw = cores // bh
-        c2 = (width // 2 - 4 * bw, height // 2 - bh, 8 * bw, 2 * bh)
-        t0 = time.time()
-        O.render_image(co, fi, cam, O.make_opts(n_coarse, n_fine, crop=c2, seed=seed, naive=True, threads=cores))
-        out["reference_loop_order_rays_per_s"] = c2[2] * c2[3] / (time.time() - t0)
-    return out
+    return {"value": n_rays / dt, "unit": "rays/s", "cores": cores, "kind": "port, reference loop order",
+            "sample": f"{c2[2]}x{c2[3]} window at ({c2[0]},{c2[1]}) of the reference CLI's 256x256 frame (src/lib.rs:657-658) = {n_rays} rays = "
+                      f"one 8x8 block (the reference's rayon task, src/lib.rs:491,533-550) per thread over {cores} threads, {n_coarse}+{n_fine} "
+                      f"samples, forward_fallback's loop nest (src/network.rs:124-147: bias fill, k-outer / batch-middle / out-inner, "
+                      f"separate mul and add), {dt:.1f} s; baseline, not target",
+            "reference_loop_order_rays_per_s": n_rays / dt, "blocked_rays_per_s": blocked, "blocked_sample": blocked_note}
+
+
+def launch_ranks(n, argv, script=None):
+    """`python bench.py --gpus N` without an outer launcher: start the N ranks as child processes (one per GPU) BEFORE this
+    process touches torch or HIP (it never does), relay rank 0's JSON line, exit non-zero if any rank fails."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, script or os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, text=True))
+    import threading
+    out0 = []
+    reader = threading.Thread(target=lambda: out0.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    failed = None
+    while failed is None and any(p.poll() is None for p in procs):
+        time.sleep(0.2)
+        for r, p in enumerate(procs):
+            if p.poll() not in (None, 0):
+                failed = (r, p.returncode)
+    for r, p in enumerate(procs):  # a failed rank leaves the others waiting in a collective: stop exactly those children
+        if p.poll() is None:
+            p.kill()
+        p.wait()
+        if p.returncode != 0 and failed is None:
+            failed = (r, p.returncode)
+    reader.join(timeout=10)
+    for ln in (out0[0] if out0 and out0[0] else "").splitlines():  # library chatter on rank 0's stdout (gloo) goes to stderr
+        print(ln, file=sys.stdout if ln.lstrip().startswith("{") else sys.stderr, flush=True)
+    if failed:
+        raise SystemExit(f"bench.py: rank {failed[0]} exited with code {failed[1]}")
 
 
 def main():
@@ -108,8 +157,11 @@ def main():
                          "renders a whole frame of its own view (independent frames of a camera path, no data-path collective)")
     ap.add_argument("--no-extra", action="store_true", help="skip the separately reported skip_empty frames (profiling runs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-naive", action="store_true", help="also time the reference's own loop order (minutes)")
+    ap.add_argument("--no-cpu-reference-order", action="store_true",
+                    help="quick runs: time only the oracle's cache-blocked nest (skips the ~2 min reference-loop-order sample)")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch_ranks(args.gpus, sys.argv[1:])
 
     import torch
     import torch.distributed as dist
@@ -131,7 +183,9 @@ def main():
     if use_dist:
         if world == 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29511")
-        backend = os.environ.get("NERF_BENCH_BACKEND", "nccl")  # nccl == RCCL on ROCm; "gloo" only to rehearse N > 1 on ONE GPU
+        # nccl == RCCL on ROCm.  RCCL refuses two ranks on one device, so a rehearsal of N ranks on fewer GPUs (a 1-GPU
+        # test box) falls back to gloo on host copies of the bands -- and says so in the JSON line.
+        backend = os.environ.get("NERF_BENCH_BACKEND", "nccl" if n_visible >= world else "gloo")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
@@ -218,6 +272,17 @@ def main():
                             "f32 accumulate; passes the f32 path's tolerances against the oracle (tests/test_gpu_parity.py); the few values "
                             "above 5e-5 are pixels where a coarse-density difference of 1e-5 relocates one fine sample (DESIGN 6, parity row)"}
         r.kernel_time_query(reset=True)
+    # The timed region leaves the frame in HBM (`value` never includes PCIe); the host-pointer entry point additionally pays
+    # one D2H copy of the frame (BASELINE.md section 4 counts it on the GPU side): measured here, reported beside `value`.
+    d2h_ms = None
+    if world == 1:
+        host_frame = torch.empty(frame.shape, dtype=frame.dtype, pin_memory=True)
+        host_frame.copy_(frame, non_blocking=True); torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        for _ in range(5):
+            host_frame.copy_(frame, non_blocking=True)
+        torch.cuda.synchronize(dev)
+        d2h_ms = 1e3 * (time.perf_counter() - t1) / 5
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev if not use_dist or dist.get_backend() == "nccl" else "cpu")
     if use_dist:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -234,9 +299,15 @@ def main():
         # executed flops of the dominant launches: a skipped sample still runs dense0..7 + alpha (sigma-only cost)
         flops_dom = pts_dom * N.FLOP_PER_POINT_FULL - n_dom * skipped_per_launch * (N.FLOP_PER_POINT_FULL - N.FLOP_PER_POINT_SIGMA)
         ach = mfma_per_flop * flops_dom / (ms_dom * 1e-3) / 1e12 if ms_dom > 0 else 0.0
+        traffic, traffic_src = pmc_traffic_bytes("void nerf_mlp_kernel_bf16v2<true" if bf16 else
+                                                 "void nerf_mlp_kernel_bf16x3<true" if x3 else "void nerf_mlp_kernel<true")
         line = {  # noqa: E501
             "metric": "rays/sec, lego 800x800 (64 coarse + 128 fine samples per ray)", "value": value, "unit": "rays/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+            "n_gpus": world, "ranks": dist.get_world_size() if use_dist else 1,
+            "backend": ((dist.get_backend() + (" (RCCL over xGMI)" if dist.get_backend() == "nccl" else
+                                                f" (REHEARSAL: {world} ranks share {n_visible} GPU(s); the collective runs on host copies)"))
+                        if use_dist else "none (single process, no collective)"),
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
             "higher_is_better": True, "scaling": "weak" if weak else "strong", "vs_baseline": None,
             "dtype": ("bf16 operands / f32 accumulate (C5 study, PSNR-level parity)" if bf16 else
                       "f32 as three-way bf16 split: 6 bf16 MFMA products per f32 product, f32 accumulate (f32-level parity)" if x3 else "f32"),
@@ -247,11 +318,15 @@ def main():
                                    f"samples/ray, {args.dtype}, {world}xMI355X" +
                                    ("" if world == 1 else ", one frame per rank, no collective" if weak else ", row bands + RCCL all-gather"),
                        "rays_per_step": n_rays, "flop_per_ray": flop_ray, "seed": args.seed,
+                       "frame": "left in HBM inside the timed region (value excludes PCIe)",
+                       "d2h_ms_per_frame": d2h_ms,
+                       "rays_per_s_including_d2h": (n_rays / (dt / args.steps + 1e-3 * d2h_ms)) if d2h_ms is not None else None,
                        "skip_empty": bool(args.skip_empty), "colour_head_skipped_samples_per_frame": skipped_per_launch,
                        "whole_job_fraction_of_mfma_roofline": mfma_per_flop * value * flop_ray / (world * peak * 1e12)},  # per-GPU average
             "roofline": {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
-                         "frac": ach / peak, "traffic": pmc_traffic_bytes("void nerf_mlp_kernel_bf16v2<true" if bf16 else
-                                                       "void nerf_mlp_kernel_bf16x3<true" if x3 else "void nerf_mlp_kernel<true"),
+                         "frac": ach / peak, "traffic": traffic,
+                         "traffic_source": (f"HBM bytes per launch from the committed rocprofv3 PMC passes ({traffic_src}; 2 x FETCH_SIZE + WRITE_SIZE "
+                                            "in separate --pmc runs), not re-measured in this run; algorithmic: 20 B/point") if traffic_src else None,
                          "kernel": ("nerf_mlp_kernel_bf16v2" if bf16
                                     else "nerf_mlp_kernel_bf16x3" if x3 else "nerf_mlp_kernel") + "<FULL=true, MODE_RAYS> (fine network)",
                          "launches": n_dom, "avg_launch_ms": ms_dom / max(n_dom, 1),
@@ -266,7 +341,7 @@ def main():
         if extra_skip:
             line["extra_skip_empty"] = extra_skip
         if world == 1 and not args.no_cpu_baseline and not bf16 and not x3:
-            line["cpu_baseline"] = cpu_baseline(args.width, args.height, args.coarse, args.fine, args.seed, args.cpu_naive)
+            line["cpu_baseline"] = cpu_baseline(args.width, args.height, args.coarse, args.fine, args.seed, not args.no_cpu_reference_order)
         print(json.dumps(line), flush=True)
     del out
     r.close()
