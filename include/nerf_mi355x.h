@@ -17,7 +17,7 @@
  * one HIP device and is single-caller: one call at a time, and consecutive asynchronous calls (`*_device`) must use the
  * same stream or be separated by a stream synchronisation -- they share the context's pass workspace.  Create one
  * context per GPU / per thread.
- * Everything is f32.  Without the HIP runtime or a gfx950 device nerf_create fails (there is no CPU fallback).
+ * All buffers at the boundary are f32 (the MLP arithmetic inside is selected by nerf_render_opts.mlp_dtype).  Without the HIP runtime or a gfx950 device nerf_create fails (there is no CPU fallback).
  */
 #ifndef NERF_MI355X_H
 #define NERF_MI355X_H
@@ -124,7 +124,7 @@ int nerf_debug_split_bf16x3(const float *values, size_t n, uint16_t *parts /* 3 
 /* host pointers, synchronous.  n == 0 is a no-op (src/network.rs:199-201). */
 int nerf_forward_batch(nerf_ctx *ctx, int which, const float *pts_soa /*3 x n*/, const float *dirs_aos /*n x 3*/,
                        size_t n, float *rgb_aos /*n x 3*/, float *sigma /*n*/);
-/* same with an explicit MLP arithmetic (NERF_MLP_F32 / NERF_MLP_BF16) */
+/* same with an explicit MLP arithmetic (NERF_MLP_F32 / NERF_MLP_BF16 / NERF_MLP_BF16X3) */
 int nerf_forward_batch_ex(nerf_ctx *ctx, int which, int mlp_dtype, const float *pts_soa, const float *dirs_aos, size_t n,
                           float *rgb_aos, float *sigma);
 /* device pointers, asynchronous on `stream` (a hipStream_t passed as void*; NULL = default stream) */
@@ -139,6 +139,25 @@ int nerf_render_image(nerf_ctx *ctx, const nerf_camera *cam, const nerf_render_o
 /* device output, asynchronous on `stream`; stats != NULL synchronises the stream before returning. */
 int nerf_render_image_device(nerf_ctx *ctx, const nerf_camera *cam, const nerf_render_opts *opts, float *d_rgb_out,
                              void *stream, nerf_stats *stats);
+/* ---- S3 over several GPUs of one node (reference: the rayon fan-out over blocks + scatter, src/lib.rs:533-557) ------
+ * ctxs[i] is one context per device (nerf_create / nerf_create_multi), each with both networks loaded (weights are
+ * replicated).  Context i renders a contiguous band of the output rows -- band i of n: first row i*(h/n) + min(i, h%n),
+ * h/n + (i < h%n) rows -- on its own host thread and stream; a band is bit-identical to the same rows of a single-context
+ * frame (per-pixel counter RNG).  `gather` selects how the bands meet in rgb_out (host, same layout as nerf_render_image):
+ *   NERF_GATHER_HOST  each band is copied device -> host into its rows directly (no GPU-to-GPU traffic);
+ *   NERF_GATHER_PEER  bands are copied GPU -> GPU over xGMI (hipMemcpyPeerAsync) into a frame on ctxs[0]'s device, then one D2H;
+ *   NERF_GATHER_RCCL  ONE ncclAllGather of the bands (RCCL over xGMI; librccl is dlopen'ed on first use): the whole frame
+ *                     ends up on every device, then one D2H from ctxs[0].  Needs distinct devices.
+ * Synchronous.  per_ctx (n entries) may be NULL.  Several contexts may share a device (tests; no speed-up).  Not re-entrant
+ * for the same contexts.  Errors of any band are reported on ctxs[0]. */
+enum { NERF_GATHER_HOST = 0, NERF_GATHER_PEER = 1, NERF_GATHER_RCCL = 2 };
+int nerf_render_image_multi(nerf_ctx *const *ctxs, int n, const nerf_camera *cam, const nerf_render_opts *opts, int gather,
+                            float *rgb_out, nerf_stats *per_ctx /* n entries or NULL */);
+/* n contexts, device_ids[i] each (NULL => devices 0..n-1); all-or-nothing. */
+int nerf_create_multi(const int *device_ids, int n, nerf_ctx **out /* n entries */);
+/* Frees the cached RCCL communicators of NERF_GATHER_RCCL (optional; call after the contexts are idle). */
+void nerf_multi_release(void);
+
 /* Accumulated device time of the dominant (fine- or coarse-only-MLP) kernel since the last reset: blocks until the
  * recorded events have completed.  Used by bench.py for the roofline line. */
 int nerf_kernel_time_query(nerf_ctx *ctx, double *ms_dominant_mlp, uint64_t *points_dominant_mlp, uint32_t *n_launches,

@@ -63,6 +63,10 @@ PROTOTYPES = {
     "nerf_render_image": (C.c_int, [C.c_void_p, C.POINTER(CCamera), C.POINTER(COpts), f32p, C.POINTER(CStats)]),
     "nerf_render_image_device": (C.c_int, [C.c_void_p, C.POINTER(CCamera), C.POINTER(COpts), C.c_void_p, C.c_void_p,
                                            C.POINTER(CStats)]),
+    "nerf_render_image_multi": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.POINTER(CCamera), C.POINTER(COpts), C.c_int, f32p,
+                                          C.POINTER(CStats)]),
+    "nerf_create_multi": (C.c_int, [C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p)]),
+    "nerf_multi_release": (None, []),
     "nerf_kernel_time_query": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64),
                                          C.POINTER(C.c_uint32), C.c_int]),
     "nerf_debug_shader_clock_mhz": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),

@@ -247,6 +247,31 @@ def render_image(coarse, fine, camera, fine_samples_per_ray=128, *, seed=0, coar
     return (out, Stats(st)) if return_stats else out
 
 
+GATHER_HOST, GATHER_PEER, GATHER_RCCL = 0, 1, 2
+_GATHERS = {"host": 0, "peer": 1, "rccl": 2, 0: 0, 1: 1, 2: 2}
+
+
+def render_image_multi(renderers, camera, fine_samples_per_ray=128, *, gather="host", seed=0, coarse_only=False, crop=None,
+                       ssaa=1, dtype="f32", skip_empty=False, return_stats=False):
+    """render_image fanned out over several Renderers (one per GPU) inside ONE process, through nerf_render_image_multi:
+    row bands on per-context host threads + streams, gathered by direct D2H ("host"), GPU-to-GPU peer copies ("peer") or one
+    RCCL all-gather ("rccl").  The reference's counterpart is the rayon fan-out + scatter of src/lib.rs:533-557.
+    Every Renderer must have both networks loaded."""
+    L = _lib.load_library()
+    n = len(renderers)
+    handles = (C.c_void_p * n)(*[r.handle for r in renderers])
+    opts = RenderOpts(camera.samples_per_ray, fine_samples_per_ray, coarse_only, crop, ssaa, seed, dtype, skip_empty)
+    o = opts.to_c()
+    shape = opts.out_shape(camera)
+    if shape[0] <= 0 or shape[1] <= 0:
+        raise NerfError(-1, "crop window outside the frame")
+    out = np.empty(shape, np.float32)
+    st = (CStats * n)()
+    check(L.nerf_render_image_multi(handles, n, C.byref(camera.c), C.byref(o), _GATHERS[gather], _p(out), st if return_stats else None),
+          renderers[0].handle if n else None)
+    return (out, [Stats(s) for s in st]) if return_stats else out
+
+
 def quantize_rgb8(pixels):
     a = _f32(pixels)
     out = np.empty(a.shape, np.uint8)

@@ -23,50 +23,13 @@
 
 using namespace nerfhost;
 
-namespace {
+#include "nerf_internal.h"
+
+using namespace nerfint;
+
+namespace nerfint {
 
 thread_local std::string g_err; // context-free calls
-
-struct DevNet {
-    float *wstream = nullptr, *small = nullptr;
-    uint16_t *wstream_bf16v2 = nullptr; // bf16 pieces in output-tile-major order (mlp_kernel_bf16v2.hip)
-    uint16_t *wstream_x3 = nullptr;     // three bf16 parts per weight (mlp_kernel_bf16x3.hip)
-    bool loaded = false;
-};
-
-struct EvPair {
-    hipEvent_t a, b;
-    int kind; // 0 coarse mlp, 1 fine mlp (dominant), 2 other
-    uint64_t points;
-};
-
-} // namespace
-
-struct nerf_ctx {
-    int device = 0;
-    int n_cus = 0;
-    std::string arch;
-    std::string err;
-    hipStream_t stream = nullptr; // used by the host-pointer entry points
-    DevNet net[2];
-    // pass workspace
-    size_t ws_rays = 0, ws_nc = 0, ws_m = 0;
-    float *d_dirs = nullptr, *d_tc = nullptr, *d_sc = nullptr, *d_rgbc = nullptr, *d_tf = nullptr, *d_sf = nullptr,
-          *d_rgbf = nullptr;
-    float *d_rayfb = nullptr; size_t rayfb_floats = 0; // SSAA ray framebuffer
-    float *d_out = nullptr; size_t out_floats = 0;       // host-pointer render output staging
-    // scratch for forward_batch / stage calls
-    void *d_scratch = nullptr; size_t scratch_bytes = 0;
-    unsigned long long *d_skip = nullptr;  // device counter of skipped 128-point tiles (skip_empty)
-    unsigned long long *d_clock = nullptr; // diagnostic: per-workgroup {cycles, 100 MHz ticks} of the last fine-MLP launch
-    bool clock_valid = false;
-    size_t max_rays_per_pass = (size_t)1 << 20;
-    std::vector<hipEvent_t> ev_pool;
-    std::vector<EvPair> last_render; // events of the last render
-    std::vector<EvPair> dominant;    // accumulated dominant-kernel events (nerf_kernel_time_query)
-};
-
-namespace {
 
 int fail(nerf_ctx *c, int code, const std::string &msg) {
     if (c) c->err = msg;
@@ -74,22 +37,9 @@ int fail(nerf_ctx *c, int code, const std::string &msg) {
     return code;
 }
 
-#define HIP_TRY(c, expr)                                                                                    \
-    do {                                                                                                    \
-        hipError_t _e = (expr);                                                                             \
-        if (_e != hipSuccess)                                                                               \
-            return fail((c), NERF_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));              \
-    } while (0)
+} // namespace nerfint
 
-struct DeviceGuard { // a context is bound to one device; entry points may be called with another one current
-    int prev = -1;
-    bool ok;
-    explicit DeviceGuard(int dev) {
-        ok = hipGetDevice(&prev) == hipSuccess;
-        if (ok && prev != dev) ok = hipSetDevice(dev) == hipSuccess; else if (ok) prev = -1;
-    }
-    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
-};
+namespace {
 
 hipEvent_t get_event(nerf_ctx *c) {
     if (!c->ev_pool.empty()) { hipEvent_t e = c->ev_pool.back(); c->ev_pool.pop_back(); return e; }
@@ -112,13 +62,17 @@ void recycle_dominant(nerf_ctx *c, size_t keep) {
     }
 }
 
-int ensure_bytes(nerf_ctx *c, void **p, size_t *cur, size_t need) {
+} // namespace
+
+int nerfint::ensure_bytes(nerf_ctx *c, void **p, size_t *cur, size_t need) {
     if (*cur >= need) return NERF_OK;
     if (*p) { HIP_TRY(c, hipDeviceSynchronize()); HIP_TRY(c, hipFree(*p)); *p = nullptr; *cur = 0; }
     HIP_TRY(c, hipMalloc(p, need));
     *cur = need;
     return NERF_OK;
 }
+
+namespace {
 
 int ensure_workspace(nerf_ctx *c, size_t rays, size_t nc, size_t m) {
     if (rays <= c->ws_rays && nc <= c->ws_nc && m <= c->ws_m) return NERF_OK;
@@ -274,8 +228,10 @@ struct Timed {
     }
 };
 
-int render_device(nerf_ctx *c, const nerf_camera *cam, const nerf_render_opts *o, float *d_out, hipStream_t st,
-                  nerf_stats *stats) {
+} // namespace
+
+int nerfint::render_device(nerf_ctx *c, const nerf_camera *cam, const nerf_render_opts *o, float *d_out, hipStream_t st,
+                           nerf_stats *stats) {
     int rc;
     if ((rc = check_camera(c, cam))) return rc;
     if (!o) return fail(c, NERF_ERR_INVALID, "opts is NULL");
@@ -417,14 +373,12 @@ int render_device(nerf_ctx *c, const nerf_camera *cam, const nerf_render_opts *o
     return NERF_OK;
 }
 
-} // namespace
-
 // ================================================================================================
 // extern "C"
 // ================================================================================================
 extern "C" {
 
-int nerf_abi_version(void) { return 1; }
+int nerf_abi_version(void) { return 2; }
 
 const char *nerf_last_error(const nerf_ctx *ctx) { return ctx ? ctx->err.c_str() : g_err.c_str(); }
 

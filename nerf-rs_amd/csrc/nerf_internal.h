@@ -1,0 +1,80 @@
+// nerf_internal.h -- the context and the helpers shared by nerf_api.cpp (single-device entry points) and
+// nerf_multi.cpp (multi-GPU fan-out).  Internal to libnerf_mi355x.so; nothing here is part of the C ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/nerf_mi355x.h"
+
+namespace nerfint {
+
+struct DevNet {
+    float *wstream = nullptr, *small = nullptr;
+    uint16_t *wstream_bf16v2 = nullptr; // bf16 pieces in output-tile-major order (mlp_kernel_bf16v2.hip)
+    uint16_t *wstream_x3 = nullptr;     // three bf16 parts per weight (mlp_kernel_bf16x3.hip)
+    bool loaded = false;
+};
+
+struct EvPair {
+    hipEvent_t a, b;
+    int kind; // 0 coarse mlp, 1 fine mlp (dominant), 2 other
+    uint64_t points;
+};
+
+} // namespace nerfint
+
+struct nerf_ctx {
+    int device = 0;
+    int n_cus = 0;
+    std::string arch;
+    std::string err;
+    hipStream_t stream = nullptr; // used by the host-pointer entry points
+    nerfint::DevNet net[2];
+    // pass workspace
+    size_t ws_rays = 0, ws_nc = 0, ws_m = 0;
+    float *d_dirs = nullptr, *d_tc = nullptr, *d_sc = nullptr, *d_rgbc = nullptr, *d_tf = nullptr, *d_sf = nullptr,
+          *d_rgbf = nullptr;
+    float *d_rayfb = nullptr; size_t rayfb_floats = 0; // SSAA ray framebuffer
+    float *d_out = nullptr; size_t out_floats = 0;       // host-pointer render output staging
+    // scratch for forward_batch / stage calls
+    void *d_scratch = nullptr; size_t scratch_bytes = 0;
+    unsigned long long *d_skip = nullptr;  // device counter of skipped 128-point tiles (skip_empty)
+    unsigned long long *d_clock = nullptr; // diagnostic: per-workgroup {cycles, 100 MHz ticks} of the last fine-MLP launch
+    bool clock_valid = false;
+    size_t max_rays_per_pass = (size_t)1 << 20;
+    std::vector<hipEvent_t> ev_pool;
+    std::vector<nerfint::EvPair> last_render; // events of the last render
+    std::vector<nerfint::EvPair> dominant;    // accumulated dominant-kernel events (nerf_kernel_time_query)
+};
+
+namespace nerfint {
+
+// records the message on the context (if any) and for nerf_last_error(NULL) of this thread; returns `code`
+int fail(nerf_ctx *c, int code, const std::string &msg);
+
+#define HIP_TRY(c, expr)                                                                                    \
+    do {                                                                                                    \
+        hipError_t _e = (expr);                                                                             \
+        if (_e != hipSuccess)                                                                               \
+            return fail((c), NERF_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));              \
+    } while (0)
+
+struct DeviceGuard { // a context is bound to one device; entry points may be called with another one current
+    int prev = -1;
+    bool ok;
+    explicit DeviceGuard(int dev) {
+        ok = hipGetDevice(&prev) == hipSuccess;
+        if (ok && prev != dev) ok = hipSetDevice(dev) == hipSuccess; else if (ok) prev = -1;
+    }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
+int ensure_bytes(nerf_ctx *c, void **p, size_t *cur, size_t need);
+// render_image on the context's device, asynchronous on `st` (synchronises only when stats != NULL)
+int render_device(nerf_ctx *c, const nerf_camera *cam, const nerf_render_opts *o, float *d_out, hipStream_t st,
+                  nerf_stats *stats);
+
+} // namespace nerfint

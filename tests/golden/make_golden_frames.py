@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""Whole-frame fixtures from the CPU oracle (oracle/nerf_oracle.c) for the GPU suite, which cannot run the oracle at
+this size (the GPU box has no /root/reference and the -m gpu suite must stay short).
+
+    python tests/golden/make_golden_frames.py [threads]     # ~45 min on 8 cores; rewrites the two files below
+
+  frame_c3_800_seed0.npz   BASELINE config C3 (lego 800x800, 64 + 128 samples/ray, f32), seed 0: the oracle's whole frame
+                           (`image`, 800 x 800 x 3 f32 linear RGB) and its save_ppm quantisation (`rgb8`, src/lib.rs:573-577)
+  frame_gates.json         PSNR numbers of the north star's Gate 2, all against A = that seed-0 frame:
+                             cpu_seed1_vs_A            the oracle's seed-1 frame (the jitter noise floor, ~40 dB)
+                             cpu_ssaa2_seed1_vs_A      the oracle's seed-1 frame at BASELINE config C5's geometry (800x800 output,
+                                                       2x2 rays per pixel = 1600x1600 = 2 560 000 rays, box filter)
+Same chain of trust as make_golden.py: the oracle's MLP is pinned by the reference's 120 golden scalars; the frame is the
+oracle's line-by-line restatement of render_image (src/lib.rs:474-565) with the seeded counter RNG.
+"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import oracle_py as O  # noqa: E402
+
+SCENE = os.path.join(ROOT, "lego_rust")
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+def psnr(a, b):
+    mse = float(np.mean((np.clip(a, 0, 1).astype(np.float64) - np.clip(b, 0, 1).astype(np.float64)) ** 2))
+    return 10.0 * np.log10(1.0 / mse)
+
+
+def main():
+    threads = int(sys.argv[1]) if len(sys.argv) > 1 else len(os.sched_getaffinity(0))
+    S = O.load_samples(os.path.join(SCENE, "tf_reference_samples.json"))
+    co, fi = O.Net(os.path.join(SCENE, "coarse")), O.Net(os.path.join(SCENE, "fine"))
+    cam = O.camera_from_samples(S, 800, 800)
+    gates = {"config": "lego 800x800, 64 + 128 samples/ray, f32 oracle; A = seed-0 frame (frame_c3_800_seed0.npz)"}
+    t0 = time.time()
+    a = O.render_image(co, fi, cam, O.make_opts(64, 128, seed=0, threads=threads))
+    gates["oracle_seconds_seed0"] = round(time.time() - t0, 1); gates["oracle_threads"] = threads
+    np.savez_compressed(os.path.join(OUT, "frame_c3_800_seed0.npz"), image=a, rgb8=O.quantize_rgb8(a), seed=np.uint64(0),
+                        n_coarse=64, n_fine=128, width=800, height=800)
+    print("seed 0 frame written after %.0f s; white fraction %.4f" % (time.time() - t0, float((a == 1.0).all(axis=2).mean())), flush=True)
+    b = O.render_image(co, fi, cam, O.make_opts(64, 128, seed=1, threads=threads))
+    gates["cpu_seed1_vs_A"] = psnr(b, a)
+    json.dump(gates, open(os.path.join(OUT, "frame_gates.json"), "w"), indent=1)
+    print("seed 1:", gates["cpu_seed1_vs_A"], flush=True)
+    c = O.render_image(co, fi, cam, O.make_opts(64, 128, seed=1, ssaa=2, threads=threads))
+    gates["cpu_ssaa2_seed1_vs_A"] = psnr(c, a)
+    gates["oracle_seconds_total"] = round(time.time() - t0, 1)
+    json.dump(gates, open(os.path.join(OUT, "frame_gates.json"), "w"), indent=1)
+    print("ssaa2 seed 1:", gates["cpu_ssaa2_seed1_vs_A"], "total %.0f s" % (time.time() - t0), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,112 @@
+"""Multi-GPU behind the C ABI (nerf_render_image_multi): row bands on per-context host threads + streams, gathered into one
+framebuffer with no torch involved.  The test box has ONE MI355X, so the contexts share device 0: that exercises the band
+split, the threads, the three gather paths' bookkeeping and the ragged cases; the result must be BIT-IDENTICAL to the
+single-context frame (per-pixel counter RNG).  The RCCL gather needs distinct devices (RCCL refuses two ranks on one GPU):
+it runs here at n = 1 and must refuse n = 2 on one device with a clear message."""
+import subprocess
+import sys
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, SCENE, golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def three(native):
+    rs = [native.Renderer(0) for _ in range(3)]
+    for r in rs:
+        r.load_scene(SCENE)
+    yield rs
+    for r in rs:
+        r.close()
+
+
+@pytest.mark.parametrize("gather", ["host", "peer"])
+@pytest.mark.parametrize("n", [1, 2, 3])
+def test_multi_bands_are_bit_identical_to_one_context(native, renderer, samples, three, n, gather):
+    cam = native.camera_from_samples(samples, 800, 800, 64)
+    crop = (200, 300, 400, 101)                       # 101 rows: 51+50 over 2 contexts, 34+34+33 over 3 (ragged)
+    ref = native.render_image(renderer.coarse, renderer.fine, cam, 128, seed=0, crop=crop)
+    img, st = native.render_image_multi(three[:n], cam, 128, gather=gather, seed=0, crop=crop, return_stats=True)
+    assert np.array_equal(img, ref)
+    assert [s.n_rays for s in st] == [400 * native.band_of_rank(101, i, n)[1] for i in range(n)]
+    assert (np.abs(ref - 1.0) > 1e-3).mean() > 0.2    # the window really shows the model
+
+
+def test_multi_more_contexts_than_rows_and_golden_crop(native, samples, three):
+    cam = native.camera_from_samples(samples, 800, 800, 64)
+    g = golden("crop_c3_800_64_128.npz")
+    x0, y0, w, h = (int(v) for v in g["crop"])
+    img = native.render_image_multi(three, cam, 128, gather="host", seed=0, crop=(x0, y0, w, 2))   # band 2 is empty
+    d = np.abs(img - g["image"][:2])
+    assert d.max() <= 5e-4 and d.mean() <= 1e-5       # Gate 1 against the oracle fixture
+    img = native.render_image_multi(three, cam, 128, gather="peer", seed=0, crop=(x0, y0, w, h), dtype="bf16x3", skip_empty=True)
+    d = np.abs(img - g["image"])
+    assert np.quantile(d, 0.999) <= 2e-5 and d.max() <= 2e-3
+
+
+def test_multi_whole_frame_three_contexts(native, renderer, samples, three):
+    cam = native.camera_from_samples(samples, 800, 800, 64)
+    ref = native.render_image(renderer.coarse, renderer.fine, cam, 128, seed=0)
+    img, st = native.render_image_multi(three, cam, 128, gather="peer", seed=0, return_stats=True)
+    assert np.array_equal(img, ref)
+    assert sum(s.n_rays for s in st) == 640000 and [s.n_rays // 800 for s in st] == [267, 267, 266]
+    ss = native.render_image_multi(three[:2], cam, 128, gather="host", seed=0, ssaa=2, crop=(380, 360, 24, 9), dtype="bf16")
+    one = native.render_image(renderer.coarse, renderer.fine, cam, 128, seed=0, ssaa=2, crop=(380, 360, 24, 9), dtype="bf16")
+    assert np.array_equal(ss, one)                    # bands of SSAA pixels: whole output rows per context
+
+
+def test_multi_rccl_gather(native, renderer, samples, three):
+    cam = native.camera_from_samples(samples, 800, 800, 64)
+    crop = (368, 352, 64, 7)
+    ref = native.render_image(renderer.coarse, renderer.fine, cam, 128, seed=0, crop=crop)
+    img = native.render_image_multi(three[:1], cam, 128, gather="rccl", seed=0, crop=crop)       # one rank: ncclCommInitAll + all-gather
+    assert np.array_equal(img, ref)
+    with pytest.raises(native.NerfError) as e:
+        native.render_image_multi(three[:2], cam, 128, gather="rccl", seed=0, crop=crop)
+    assert e.value.code == -1 and "distinct device" in e.value.msg
+    native.load_library().nerf_multi_release()
+
+
+def test_multi_argument_errors(native, samples, three):
+    cam = native.camera_from_samples(samples, 64, 64, 64)
+    with pytest.raises(native.NerfError) as e:
+        native.render_image_multi([three[0], three[0]], cam, 128)
+    assert e.value.code == -1 and "listed twice" in e.value.msg
+    with pytest.raises(native.NerfError):
+        native.render_image_multi([], cam, 128)
+    with pytest.raises(native.NerfError) as e:
+        native.render_image_multi(three[:2], cam, 128, crop=(0, 0, 65, 3))
+    assert "crop window outside the frame" in e.value.msg
+    with native.Renderer(0) as empty:                 # a band's failure (network not loaded) surfaces on the call
+        with pytest.raises(native.NerfError) as e:
+            native.render_image_multi([three[0], empty], cam, 128)
+        assert e.value.code == -6 and "not loaded" in e.value.msg
+
+
+def test_create_multi(native):
+    import ctypes as C
+    L = native.load_library()
+    hs = (C.c_void_p * 2)()
+    assert L.nerf_create_multi((C.c_int * 2)(0, 0), 2, hs) == 0 and hs[0] and hs[1] and hs[0] != hs[1]
+    L.nerf_destroy(hs[0]); L.nerf_destroy(hs[1])
+    assert L.nerf_create_multi((C.c_int * 2)(0, 99), 2, hs) == -1 and not hs[0] and not hs[1]    # all-or-nothing
+
+
+def test_bench_self_launches_two_ranks_on_this_gpu():
+    """`python bench.py --gpus 2` with NO outer launcher (the driver's scaling command): the parent starts the ranks, both
+    render their band on the one GPU of this box, the gather is rehearsed over gloo (RCCL refuses two ranks per device)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--width", "96",
+                        "--height", "80", "--no-extra", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["ranks"] == 2 and d["backend"].startswith("gloo") and "REHEARSAL" in d["backend"]
+    assert d["value"] > 0 and d["scaling"] == "strong" and d["config"]["rays_per_step"] == 96 * 80

@@ -27,7 +27,7 @@ def test_abi_exports_every_declared_symbol(native):
         assert hasattr(L, name), f"{name} declared in the header but not exported"
         assert name in _lib.PROTOTYPES, f"{name} has no ctypes prototype"
     assert set(_lib.PROTOTYPES) == declared
-    assert native.load_library().nerf_abi_version() == 1
+    assert native.load_library().nerf_abi_version() == 2
 
 
 def test_no_device_means_loud_failure(native):
