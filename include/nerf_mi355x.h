@@ -68,12 +68,20 @@ typedef struct {
                            * operands / f32 accumulate on the bf16 matrix cores -- BASELINE config C5; PSNR-level parity).
                            * NERF_MLP_BF16X3 (2, opt-in): f32-accurate arithmetic on the bf16 matrix cores -- every weight and
                            * activation is split into three bf16 parts (exact to 2^-27) and a product is the sum of the six
-                           * significant bf16 x bf16 products, accumulated in f32; meets the f32 path's tolerances */
+                           * significant bf16 x bf16 products, accumulated in f32.  In a hierarchical render the coarse
+                           * (sampling) pass stays on the exact-f32 kernel so that the fine sample positions equal the f32
+                           * path's bit for bit; the fine (colour) pass runs in bf16x3.  Meets the f32 path's tolerances. */
     int32_t skip_empty;   /* ext: 1 = skip the colour head (bottleneck + viewdirs + rgb, 17 % of a full MLP
                            * evaluation) for every workgroup tile (128 samples in f32, 256 in bf16) whose densities are all 0.
                            * EXACT: such samples have alpha = 0 and weight 0, the image is bit-identical; only the work
                            * changes.  Default 0 so that timings are plain executed-FLOP figures. */
-    int32_t reserved[2];  /* must be 0 */
+    int32_t skip_dead;    /* ext (the rest of it; NERF_MLP_F32 only): 1 = evaluate only what can reach a pixel.
+                           * Rays are walked front to back in chunks of 32 samples; a ray is retired at the reference's
+                           * T < 1e-4 cut (src/lib.rs:276-279: every later weight is exactly 0), and the colour head runs only
+                           * on the samples whose weight is > 0 (compacted through HBM, second launch).  EXACT: the image is
+                           * bit-identical to skip_dead = 0.  Takes precedence over skip_empty.  Default 0 so that timings are
+                           * plain executed-FLOP figures; nerf_stats.n_exec_* report the evaluations actually executed. */
+    int32_t reserved[1];  /* must be 0 */
 } nerf_render_opts;
 
 /* Device-side timing of the last render (HIP events on the render stream). */
@@ -86,6 +94,10 @@ typedef struct {
     uint32_t n_mlp_launches;
     uint32_t n_passes;
     uint64_t n_colour_skipped_points; /* samples whose colour head was skipped (skip_empty) */
+    /* MLP evaluations actually executed (equal to the point counts above unless skip_empty / skip_dead removed work): */
+    uint64_t n_exec_coarse_trunk;  /* coarse network, dense0..7 + alpha */
+    uint64_t n_exec_fine_trunk;    /* fine network, dense0..7 + alpha */
+    uint64_t n_exec_colour;        /* bottleneck + viewdirs + rgb (fine network, or the coarse one when coarse_only) */
 } nerf_stats;
 
 /* ---- lifecycle ------------------------------------------------------------------------------------------ */

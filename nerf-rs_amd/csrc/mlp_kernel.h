@@ -35,3 +35,38 @@ hipError_t nerf_mlp_bf16v2_launch(const MlpArgs &a, bool full, int n_blocks, hip
 // f32 by three-way bf16 split (mlp_kernel_bf16x3.hip): a.wstream is the three-part stream (mlp_layout.h kChunks*X3)
 hipError_t nerf_mlp_bf16x3_init();
 hipError_t nerf_mlp_bf16x3_launch(const MlpArgs &a, bool full, int n_blocks, hipStream_t stream);
+
+// ---- exact dead-sample skipping (mlp_kernel_seq.hip; f32 only) -------------------------------------------------------
+// Ray-sequential trunk: waves take rays from a device-side queue and walk each ray's samples front to back in chunks of 32,
+// stopping at the reference's T < 1e-4 cut (src/lib.rs:276-279).  sigma_out must be zero-filled by the caller (samples behind
+// the cut are never written).  With export_live the trunk output of every sample with weight > 0 goes to `h8` (compacted,
+// 1 KiB per sample; capacity = all samples of the launch, nerf_seq_h8_bytes) for nerf_colour_launch.
+struct SeqArgs {
+    const float *wstream;      // the f32 packed weight stream (sigma part is used)
+    const float *small_params;
+    int n_rays, samples_per_ray;
+    const float *ray_dirs;     // n_rays x 3, unit
+    const float *t;            // n_rays x samples_per_ray, ascending
+    float origin[3];
+    float far_;
+    float *sigma_out;          // n_rays x samples_per_ray
+    unsigned int *ray_counter; // zeroed before the launch
+    unsigned int *live_count;  // zeroed before the launch (export_live)
+    float *h8;
+    unsigned int *slot_point;  // sample index (ray * samples_per_ray + k) of every exported slot
+    unsigned long long *stats; // optional: += number of 32-sample chunks evaluated
+};
+struct ColourArgs {
+    const float *wstream;      // the same stream (bottleneck + viewdirs part is used)
+    const float *small_params;
+    const unsigned int *live_count;
+    const float *h8;
+    const unsigned int *slot_point;
+    const float *ray_dirs;
+    int samples_per_ray;
+    float *rgb_out;            // n x 3, scattered by sample index; zero-filled by the caller
+};
+hipError_t nerf_seq_init();
+size_t nerf_seq_h8_bytes(size_t n_samples);
+hipError_t nerf_trunk_seq_launch(const SeqArgs &a, bool export_live, int n_blocks, hipStream_t stream);
+hipError_t nerf_colour_launch(const ColourArgs &a, int n_blocks, hipStream_t stream);

@@ -241,7 +241,15 @@ int nerfint::render_device(nerf_ctx *c, const nerf_camera *cam, const nerf_rende
     for (int r : o->reserved) if (r != 0) return fail(c, NERF_ERR_INVALID, "reserved option fields must be 0");
     if (!valid_dtype(o->mlp_dtype)) return fail(c, NERF_ERR_INVALID, "mlp_dtype must be NERF_MLP_F32, NERF_MLP_BF16 or NERF_MLP_BF16X3");
     const int dtype = o->mlp_dtype;
+    // bf16x3: the sampling pass (coarse sigma -> CDF -> fine sample positions) stays on the exact-f32 MFMA kernel, so the fine
+    // samples sit where the f32 path puts them bit for bit (a 1e-5 density difference can move a CDF entry across a fixed
+    // uniform draw and relocate a sample -- a discontinuity, not an accuracy problem); only the colour-producing pass runs in
+    // the three-way split arithmetic.
+    const int dtype_coarse = (dtype == NERF_MLP_BF16X3 && !o->coarse_only) ? NERF_MLP_F32 : dtype;
     if (o->skip_empty != 0 && o->skip_empty != 1) return fail(c, NERF_ERR_INVALID, "skip_empty must be 0 or 1");
+    if (o->skip_dead != 0 && o->skip_dead != 1) return fail(c, NERF_ERR_INVALID, "skip_dead must be 0 or 1");
+    if (o->skip_dead && dtype != NERF_MLP_F32) return fail(c, NERF_ERR_INVALID, "skip_dead is implemented for NERF_MLP_F32 only");
+    const bool seq = o->skip_dead != 0;
     if (!c->net[NERF_NET_COARSE].loaded) return fail(c, NERF_ERR_STATE, "coarse network not loaded");
     if (!o->coarse_only && !c->net[NERF_NET_FINE].loaded) return fail(c, NERF_ERR_STATE, "fine network not loaded");
     const int s = o->ssaa > 1 ? o->ssaa : 1;
@@ -258,7 +266,9 @@ int nerfint::render_device(nerf_ctx *c, const nerf_camera *cam, const nerf_rende
         return fail(c, NERF_ERR_INVALID, "too many samples per ray for the sampling / compositing kernels (one ray per wave in LDS)");
     const int RW = cw * s, RH = ch * s, RX0 = x0 * s, RY0 = y0 * s;
     // a pass must keep rays * samples within int32 (kernel indices) as well as within the configured budget
-    const size_t pass_cap = std::min<size_t>(c->max_rays_per_pass, (size_t)0x3fffffff / (size_t)M);
+    size_t pass_cap = std::min<size_t>(c->max_rays_per_pass, (size_t)0x3fffffff / (size_t)M);
+    // skip_dead: the compacted trunk outputs are sized for the worst case (every sample of a pass live, 1 KiB each)
+    if (seq) pass_cap = std::min<size_t>(pass_cap, std::max<size_t>(1, c->max_export_bytes / ((size_t)M * 1024)));
     if ((size_t)RW > pass_cap && (size_t)RW * M > (size_t)0x3fffffff) return fail(c, NERF_ERR_INVALID, "ray row too wide for one pass");
     const size_t rows_per_pass = std::max<size_t>(1, std::min<size_t>(RH, pass_cap / (size_t)RW));
     if ((rc = ensure_workspace(c, rows_per_pass * RW, nc, M))) return rc;
@@ -266,6 +276,19 @@ int nerfint::render_device(nerf_ctx *c, const nerf_camera *cam, const nerf_rende
     if (s > 1) {
         if ((rc = ensure_bytes(c, (void **)&c->d_rayfb, &c->rayfb_floats, (size_t)RW * RH * 3 * sizeof(float)))) return rc;
         ray_out = c->d_rayfb;
+    }
+    const uint32_t n_passes_total = (uint32_t)((RH + rows_per_pass - 1) / rows_per_pass);
+    if (seq) { // per MLP launch: {u32 ray queue head, u32 live-sample count, u64 evaluated 32-sample chunks}
+        const size_t slots = (size_t)n_passes_total * 2;
+        if (slots > c->seq_slots) {
+            size_t bytes = c->seq_slots * 16;
+            if ((rc = ensure_bytes(c, (void **)&c->d_seq, &bytes, slots * 16))) return rc;
+            c->seq_slots = slots;
+        }
+        HIP_TRY(c, hipMemsetAsync(c->d_seq, 0, slots * 16, st));
+        const size_t pass_samples = rows_per_pass * RW * (size_t)M;
+        if ((rc = ensure_bytes(c, (void **)&c->d_h8, &c->h8_bytes, nerf_seq_h8_bytes(pass_samples)))) return rc;
+        if ((rc = ensure_bytes(c, (void **)&c->d_slot_point, &c->slot_point_bytes, (pass_samples + 128) * sizeof(unsigned int)))) return rc;
     }
     recycle_render(c);
     recycle_dominant(c, 4096); // bound the backlog if the caller never queries
@@ -284,18 +307,46 @@ int nerfint::render_device(nerf_ctx *c, const nerf_camera *cam, const nerf_rende
             HIP_TRY(c, launch_stratified(g, nc, cam->near_, cam->far_, o->seed, c->d_tc, st));
             t.done(c->last_render);
         }
+        // skip_dead: one network over the rays of this pass as ray-sequential trunk [+ colour head on the live samples]
+        auto seq_pass = [&](const DevNet &net, int spr, const float *t_in, float *sigma_out, float *rgb_out, int slot, int kind_trunk) -> int {
+            unsigned int *ctr = c->d_seq + 4 * (size_t)slot;
+            HIP_TRY(c, hipMemsetAsync(sigma_out, 0, (size_t)n_rays * spr * sizeof(float), st)); // samples behind the cut stay 0
+            if (rgb_out) HIP_TRY(c, hipMemsetAsync(rgb_out, 0, (size_t)n_rays * spr * 3 * sizeof(float), st)); // weight-0 samples: 0 * 0
+            SeqArgs q{};
+            q.wstream = net.wstream; q.small_params = net.small; q.n_rays = n_rays; q.samples_per_ray = spr;
+            q.ray_dirs = c->d_dirs; q.t = t_in; q.far_ = cam->far_;
+            q.origin[0] = cam->pos[0]; q.origin[1] = cam->pos[1]; q.origin[2] = cam->pos[2];
+            q.sigma_out = sigma_out; q.ray_counter = ctr; q.live_count = ctr + 1; q.h8 = c->d_h8; q.slot_point = c->d_slot_point;
+            q.stats = (unsigned long long *)(ctr + 2);
+            {
+                Timed t(c, st, kind_trunk, (uint64_t)n_rays * spr, timing);
+                HIP_TRY(c, nerf_trunk_seq_launch(q, rgb_out != nullptr, c->n_cus, st));
+                t.done(c->last_render);
+            }
+            if (rgb_out) {
+                ColourArgs k{};
+                k.wstream = net.wstream; k.small_params = net.small; k.live_count = ctr + 1; k.h8 = c->d_h8; k.slot_point = c->d_slot_point;
+                k.ray_dirs = c->d_dirs; k.samples_per_ray = spr; k.rgb_out = rgb_out;
+                Timed t(c, st, 4, 0, timing);
+                HIP_TRY(c, nerf_colour_launch(k, c->n_cus, st));
+                t.done(c->last_render);
+            }
+            return NERF_OK;
+        };
         MlpArgs a{};
         a.mode = MLP_MODE_RAYS;
         a.ray_dirs = c->d_dirs;
         a.origin[0] = cam->pos[0]; a.origin[1] = cam->pos[1]; a.origin[2] = cam->pos[2];
         // coarse network: sigma only unless its colours are composited (reference discards them, src/lib.rs:404)
-        a.wstream = stream_of(NC, dtype); a.small_params = NC.small;
+        a.wstream = stream_of(NC, dtype_coarse); a.small_params = NC.small;
         a.n_points = n_rays * nc; a.samples_per_ray = nc; a.t = c->d_tc;
         a.sigma_out = c->d_sc; a.rgb_out = c->d_rgbc;
         a.skip_empty = o->skip_empty; a.skip_counter = o->skip_empty ? c->d_skip : nullptr; // only full kernels look at it
-        {
+        if (seq) {
+            if ((rc = seq_pass(NC, nc, c->d_tc, c->d_sc, o->coarse_only ? c->d_rgbc : nullptr, 2 * (int)passes, o->coarse_only ? 1 : 0))) return rc;
+        } else {
             Timed t(c, st, o->coarse_only ? 1 : 0, (uint64_t)a.n_points, timing);
-            HIP_TRY(c, launch_mlp(c, dtype, a, o->coarse_only != 0, st));
+            HIP_TRY(c, launch_mlp(c, dtype_coarse, a, o->coarse_only != 0, st));
             t.done(c->last_render);
         }
         float *pass_out = ray_out + (size_t)row * RW * 3;
@@ -324,7 +375,9 @@ int nerfint::render_device(nerf_ctx *c, const nerf_camera *cam, const nerf_rende
         a.sigma_out = c->d_sf; a.rgb_out = c->d_rgbf;
         a.clock_out = c->d_clock; // NULL unless NERF_DEBUG_CLOCK=1
         c->clock_valid = c->d_clock != nullptr;
-        {
+        if (seq) {
+            if ((rc = seq_pass(NF, M, t_fine, c->d_sf, c->d_rgbf, 2 * (int)passes + 1, 1))) return rc;
+        } else {
             Timed t(c, st, 1, (uint64_t)a.n_points, timing);
             HIP_TRY(c, launch_mlp(c, dtype, a, true, st));
             t.done(c->last_render);
@@ -357,6 +410,9 @@ int nerfint::render_device(nerf_ctx *c, const nerf_camera *cam, const nerf_rende
                 stats->n_mlp_launches++;
                 if (o->coarse_only) { stats->ms_coarse_mlp += ms; stats->n_coarse_points += p.points; }
                 else { stats->ms_fine_mlp += ms; stats->n_fine_points += p.points; }
+            } else if (p.kind == 4) { // colour head on the compacted live samples (skip_dead)
+                stats->n_mlp_launches++;
+                if (o->coarse_only) stats->ms_coarse_mlp += ms; else stats->ms_fine_mlp += ms;
             } else stats->ms_other += ms;
         }
         if (!c->last_render.empty()) {
@@ -368,6 +424,25 @@ int nerfint::render_device(nerf_ctx *c, const nerf_camera *cam, const nerf_rende
             unsigned long long tiles = 0;
             HIP_TRY(c, hipMemcpy(&tiles, c->d_skip, sizeof tiles, hipMemcpyDeviceToHost));
             stats->n_colour_skipped_points = (uint64_t)tiles * nerfmlp::kPointsPerBlock;
+        }
+        // evaluations actually executed
+        stats->n_exec_coarse_trunk = stats->n_coarse_points;
+        stats->n_exec_fine_trunk = stats->n_fine_points;
+        stats->n_exec_colour = (o->coarse_only ? stats->n_coarse_points : stats->n_fine_points) - stats->n_colour_skipped_points;
+        if (seq) {
+            std::vector<unsigned int> h((size_t)passes * 2 * 4);
+            HIP_TRY(c, hipMemcpy(h.data(), c->d_seq, h.size() * sizeof(unsigned int), hipMemcpyDeviceToHost));
+            uint64_t chunks[2] = {0, 0}, live = 0;
+            for (uint32_t k = 0; k < passes * 2; ++k) {
+                unsigned long long ch64;
+                memcpy(&ch64, &h[4 * (size_t)k + 2], sizeof ch64);
+                chunks[k & 1] += ch64;
+                live += h[4 * (size_t)k + 1];
+            }
+            stats->n_exec_coarse_trunk = chunks[0] * 32;
+            stats->n_exec_fine_trunk = o->coarse_only ? 0 : chunks[1] * 32;
+            stats->n_exec_colour = live;
+            stats->n_colour_skipped_points = (o->coarse_only ? stats->n_coarse_points : stats->n_fine_points) - live;
         }
     }
     return NERF_OK;
@@ -404,6 +479,10 @@ int nerf_create(int device_id, nerf_ctx **out) {
         const long long v = atoll(env);
         if (v > 0) c->max_rays_per_pass = (size_t)v;
     }
+    if (const char *env = getenv("NERF_MAX_EXPORT_BYTES")) {
+        const long long v = atoll(env);
+        if (v > 0) c->max_export_bytes = (size_t)v;
+    }
     if (const char *env = getenv("NERF_DEBUG_CLOCK")) {
         if (atoi(env) > 0 && hipMalloc((void **)&c->d_clock, (size_t)c->n_cus * 2 * sizeof(unsigned long long)) != hipSuccess) c->d_clock = nullptr;
     }
@@ -411,6 +490,7 @@ int nerf_create(int device_id, nerf_ctx **out) {
     hipError_t e1 = nerf_mlp_init();
     if (e1 == hipSuccess) e1 = nerf_mlp_bf16v2_init();
     if (e1 == hipSuccess) e1 = nerf_mlp_bf16x3_init();
+    if (e1 == hipSuccess) e1 = nerf_seq_init();
     hipError_t e2 = e1 == hipSuccess ? sampling_init() : e1;
     hipError_t e3 = e2 == hipSuccess ? hipStreamCreate(&c->stream) : e2;
     if (e3 != hipSuccess) {
@@ -432,6 +512,9 @@ void nerf_destroy(nerf_ctx *c) {
     if (c->d_scratch) (void)hipFree(c->d_scratch);
     if (c->d_clock) (void)hipFree(c->d_clock);
     if (c->d_skip) (void)hipFree(c->d_skip);
+    if (c->d_seq) (void)hipFree(c->d_seq);
+    if (c->d_h8) (void)hipFree(c->d_h8);
+    if (c->d_slot_point) (void)hipFree(c->d_slot_point);
     recycle_render(c);
     recycle_dominant(c, 0);
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);

@@ -41,6 +41,12 @@ struct nerf_ctx {
     float *d_out = nullptr; size_t out_floats = 0;       // host-pointer render output staging
     // scratch for forward_batch / stage calls
     void *d_scratch = nullptr; size_t scratch_bytes = 0;
+    // skip_dead: device queue/counters {u32 ray counter, u32 live count, u64 chunk count} per MLP launch of a render, the
+    // compacted trunk outputs of the live samples and their sample indices
+    unsigned int *d_seq = nullptr; size_t seq_slots = 0;
+    float *d_h8 = nullptr; size_t h8_bytes = 0;
+    unsigned int *d_slot_point = nullptr; size_t slot_point_bytes = 0;
+    size_t max_export_bytes = (size_t)48 << 30; // budget of d_h8: bounds the rays per pass in skip_dead mode (NERF_MAX_EXPORT_BYTES)
     unsigned long long *d_skip = nullptr;  // device counter of skipped 128-point tiles (skip_empty)
     unsigned long long *d_clock = nullptr; // diagnostic: per-workgroup {cycles, 100 MHz ticks} of the last fine-MLP launch
     bool clock_valid = false;

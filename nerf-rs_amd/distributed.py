@@ -15,7 +15,7 @@ def band_of_rank(n_rows, rank, world_size):
 
 
 def render_image_distributed(coarse, fine, camera, fine_samples_per_ray=128, *, seed=0, coarse_only=False, crop=None,
-                             ssaa=1, dtype="f32", skip_empty=False, group=None, band_renderer=None, device=None, return_tensor=False):
+                             ssaa=1, dtype="f32", skip_empty=False, skip_dead=False, group=None, band_renderer=None, device=None, return_tensor=False):
     """render_image over all ranks of `group` (torch.distributed; backend nccl == RCCL on ROCm, gloo in CPU tests).
 
     Every rank returns the full (h, w, 3) frame.  `band_renderer(crop) -> ndarray (rows, w, 3)` overrides the GPU
@@ -42,7 +42,7 @@ def render_image_distributed(coarse, fine, camera, fine_samples_per_ray=128, *, 
         if rows > 0:
             stream = torch.cuda.current_stream(dev).cuda_stream
             render_image(coarse, fine, camera, fine_samples_per_ray, seed=seed, coarse_only=coarse_only, crop=band_crop,
-                         ssaa=ssaa, dtype=dtype, skip_empty=skip_empty, device_out=band.data_ptr(), stream=stream)
+                         ssaa=ssaa, dtype=dtype, skip_empty=skip_empty, skip_dead=skip_dead, device_out=band.data_ptr(), stream=stream)
     if band.device.type == "cuda" and dist.get_backend(group) != "nccl":
         # rehearsal only (e.g. gloo with several ranks on one GPU): the collective runs on host copies of the bands
         torch.cuda.current_stream(band.device).synchronize()

@@ -538,14 +538,16 @@ def test_bf16x3_forward_meets_f32_tolerances(renderer, samples, oracle_nets):
 
 
 def test_bf16x3_render_matches_oracle_crop(renderer, native, samples):
-    """The C3 crop (800x800, 64 + 128) through the bf16x3 arithmetic: the f32 path's frame tolerance, and skip_empty exact."""
+    """The C3 crop (800x800, 64 + 128) through the bf16x3 arithmetic: Gate 1 exactly as for the f32 path, and skip_empty exact.
+    (Round 1 ran the coarse pass in bf16x3 too: a 1e-5 density difference could relocate one fine sample -- max 4.8e-3 on the
+    full frame.  The sample positions now come from the f32 kernel, bit for bit.)"""
     cam = native.camera_from_samples(samples, 800, 800, 64)
     a = golden("crop_c3_800_64_128.npz")
     crop = tuple(int(v) for v in a["crop"])
     img = native.render_image(renderer.coarse, renderer.fine, cam, 128, seed=0, crop=crop, dtype="bf16x3")
     d = np.abs(img - a["image"])
     print(f"\nbf16x3 crop vs oracle: max {d.max():.2e} mean {d.mean():.2e} psnr {psnr(img, a['image']):.1f} dB")
-    assert np.quantile(d, 0.999) <= 2e-5 and d.max() <= 2e-3 and psnr(img, a["image"]) >= 80.0
+    _gate1(img, a["image"])   # the UNRELAXED f32 gate: the coarse (sampling) pass runs on the f32 kernel, the fine pass in bf16x3
     sk = native.render_image(renderer.coarse, renderer.fine, cam, 128, seed=0, crop=crop, dtype="bf16x3", skip_empty=True)
     assert np.array_equal(sk, img)
 

@@ -1,0 +1,102 @@
+"""skip_dead (the exact part of dead-work skipping): rays are walked front to back in chunks of 32 samples and
+retired at the reference's T < 1e-4 cut (src/lib.rs:276-279: every later weight is exactly 0); the colour head runs only on
+samples whose weight is > 0.  Nothing that reaches a pixel changes, so every image must be BIT-identical to the non-skipping
+render -- and is additionally held to Gate 1 against the oracle's fixtures.  nerf_stats.n_exec_* must show that work really
+was removed."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import SCENE, golden, psnr
+
+pytestmark = pytest.mark.gpu
+
+
+def _gate1(img, ref):
+    d = np.abs(img - ref)
+    assert d.max() <= 5e-4 and d.mean() <= 1e-5 and psnr(img, ref) >= 90.0, (d.max(), d.mean(), psnr(img, ref))
+
+
+def test_skip_dead_crop_is_bit_exact_and_meets_gate1(renderer, native, samples):
+    cam = native.camera_from_samples(samples, 800, 800, 64)
+    g = golden("crop_c3_800_64_128.npz")
+    crop = tuple(int(v) for v in g["crop"])
+    ref = native.render_image(renderer.coarse, renderer.fine, cam, 128, seed=0, crop=crop)
+    img, st = native.render_image(renderer.coarse, renderer.fine, cam, 128, seed=0, crop=crop, skip_dead=True, return_stats=True)
+    assert np.array_equal(img, ref)
+    _gate1(img, g["image"])
+    n = crop[2] * crop[3]
+    assert st.n_rays == n and st.n_coarse_points == 64 * n and st.n_fine_points == 192 * n
+    # this window looks at the model: rays are cut short, and only a fraction of the samples carries weight
+    assert 0.3 * st.n_fine_points < st.n_exec_fine_trunk < 0.98 * st.n_fine_points and st.n_exec_fine_trunk % 32 == 0
+    assert 0 < st.n_exec_colour < 0.7 * st.n_fine_points
+    assert st.n_exec_coarse_trunk <= st.n_coarse_points and st.n_exec_coarse_trunk % 32 == 0
+    assert st.n_colour_skipped_points == st.n_fine_points - st.n_exec_colour
+    again = native.render_image(renderer.coarse, renderer.fine, cam, 128, seed=0, crop=crop, skip_dead=True)
+    assert np.array_equal(again, img)                          # the dynamic ray queue does not leak into the result
+
+
+def test_skip_dead_variants_are_bit_exact(renderer, native, samples):
+    cam = native.camera_from_samples(samples, 800, 800, 64)
+    R = lambda **kw: native.render_image(renderer.coarse, renderer.fine, kw.pop("cam", cam), kw.pop("nf", 128), **kw)  # noqa: E731
+    crop = (250, 300, 300, 37)
+    assert np.array_equal(R(seed=5, crop=crop, skip_dead=True), R(seed=5, crop=crop))
+    # pure background: every ray runs all chunks (T stays 1), no colour work at all, exactly white
+    corner, st = native.render_image(renderer.coarse, renderer.fine, cam, 128, seed=3, crop=(0, 0, 64, 16), skip_dead=True, return_stats=True)
+    assert np.all(corner == 1.0) and st.n_exec_colour == 0 and st.n_exec_fine_trunk == st.n_fine_points
+    # coarse-only (BASELINE C1): the coarse network's colours are composited -> trunk + colour split on the coarse net
+    g = golden("crop_c1_400_coarse_only.npz")
+    cam4 = native.camera_from_samples(samples, 400, 400, 64)
+    c1 = tuple(int(v) for v in g["crop"])
+    img, st = native.render_image(renderer.coarse, renderer.fine, cam4, 0, seed=0, coarse_only=True, crop=c1, skip_dead=True, return_stats=True)
+    assert np.array_equal(img, native.render_image(renderer.coarse, renderer.fine, cam4, 0, seed=0, coarse_only=True, crop=c1))
+    _gate1(img, g["image"])
+    assert 0 < st.n_exec_colour < st.n_coarse_points and st.n_exec_fine_trunk == 0
+    # sample counts that are not multiples of the 32-sample chunk (ragged last chunk), n_fine = 0, SSAA
+    cam40 = native.camera_from_samples(samples, 800, 800, 40)
+    assert np.array_equal(R(cam=cam40, nf=50, seed=2, crop=(380, 360, 40, 24), skip_dead=True), R(cam=cam40, nf=50, seed=2, crop=(380, 360, 40, 24)))
+    cam7 = native.camera_from_samples(samples, 800, 800, 7)
+    assert np.array_equal(R(cam=cam7, nf=5, seed=2, crop=(380, 360, 40, 24), skip_dead=True), R(cam=cam7, nf=5, seed=2, crop=(380, 360, 40, 24)))
+    assert np.array_equal(R(nf=0, seed=2, crop=(380, 360, 40, 24), skip_dead=True), R(nf=0, seed=2, crop=(380, 360, 40, 24)))
+    assert np.array_equal(R(seed=2, crop=(190, 180, 20, 12), ssaa=2, skip_dead=True), R(seed=2, crop=(190, 180, 20, 12), ssaa=2))
+    # a single ray, and one row
+    assert np.array_equal(R(seed=1, crop=(400, 400, 1, 1), skip_dead=True), R(seed=1, crop=(400, 400, 1, 1)))
+    assert np.array_equal(R(seed=1, crop=(0, 400, 800, 1), skip_dead=True), R(seed=1, crop=(0, 400, 800, 1)))
+
+
+def test_skip_dead_full_frame(renderer, native, samples):
+    """BASELINE C3 at full size: bit-identical to the plain frame; Gate 1 against the oracle's whole frame when the fixture is
+    present; and the executed-work figures the bench line reports."""
+    cam = native.camera_from_samples(samples, 800, 800, 64)
+    ref = native.render_image(renderer.coarse, renderer.fine, cam, 128, seed=0)
+    img, st = native.render_image(renderer.coarse, renderer.fine, cam, 128, seed=0, skip_dead=True, return_stats=True)
+    assert np.array_equal(img, ref)
+    path = os.path.join(os.path.dirname(__file__), "golden", "frame_c3_800_seed0.npz")
+    if os.path.exists(path):
+        _gate1(img, np.load(path)["image"])
+    print(f"\nskip_dead full frame: passes {st.n_passes}, fine trunk {st.n_exec_fine_trunk / st.n_fine_points:.4f}, "
+          f"colour {st.n_exec_colour / st.n_fine_points:.4f}, coarse trunk {st.n_exec_coarse_trunk / st.n_coarse_points:.4f}, "
+          f"ms total {st.ms_total:.1f} (coarse {st.ms_coarse_mlp:.1f} fine {st.ms_fine_mlp:.1f} other {st.ms_other:.1f})")
+    assert st.n_exec_fine_trunk < 0.99 * st.n_fine_points and st.n_exec_colour < 0.3 * st.n_fine_points
+
+
+def test_skip_dead_small_export_budget_means_more_passes(native, samples, monkeypatch):
+    """The compacted trunk outputs are sized for the worst case of a pass; a small budget only means more passes."""
+    monkeypatch.setenv("NERF_MAX_EXPORT_BYTES", str(64 * 192 * 1024 * 5))      # five 64-ray rows of 192 samples
+    with native.Renderer(0) as r:
+        r.load_scene(SCENE)
+        cam = native.camera_from_samples(samples, 800, 800, 64)
+        crop = (368, 352, 64, 23)
+        img, st = native.render_image(r.coarse, r.fine, cam, 128, seed=0, crop=crop, skip_dead=True, return_stats=True)
+        assert st.n_passes == 5
+        monkeypatch.delenv("NERF_MAX_EXPORT_BYTES")
+        ref = native.render_image(r.coarse, r.fine, cam, 128, seed=0, crop=crop)
+        assert np.array_equal(img, ref)
+
+
+def test_skip_dead_argument_errors(renderer, native, samples):
+    cam = native.camera_from_samples(samples, 64, 64, 64)
+    with pytest.raises(native.NerfError) as e:
+        native.render_image(renderer.coarse, renderer.fine, cam, 128, skip_dead=True, dtype="bf16")
+    assert e.value.code == -1 and "NERF_MLP_F32 only" in e.value.msg
