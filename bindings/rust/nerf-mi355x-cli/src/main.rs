@@ -21,6 +21,7 @@ fn cstr(p: &Path) -> CString {
 fn main() {
     let root = std::env::var("NERF_SCENE_DIR").unwrap_or_else(|_| "lego_rust".to_string());
     let root = Path::new(&root);
+    sys::check_layouts().expect("libnerf_mi355x.so does not match this crate");
     let mut ctx = std::ptr::null_mut();
     check(std::ptr::null(), unsafe { sys::nerf_create(0, &mut ctx) });
     check(ctx, unsafe { sys::nerf_load_network_dir(ctx, sys::NERF_NET_COARSE, cstr(&root.join("coarse")).as_ptr()) });

@@ -133,7 +133,11 @@ int nerf_debug_pack_network_dir(const char *dir, float *wstream, size_t wstream_
 int nerf_debug_split_bf16x3(const float *values, size_t n, uint16_t *parts /* 3 n */);
 
 /* ---- S2: Network::forward_batch (src/network.rs:197-237) -------------------------------------------------- */
-/* host pointers, synchronous.  n == 0 is a no-op (src/network.rs:199-201). */
+/* host pointers, synchronous.  n == 0 is a no-op (src/network.rs:199-201).
+ * Input domain: the positional encoding evaluates sin/cos(2^k p), k <= 9, with a branch-free three-constant Cody-Waite
+ * reduction that is accurate (<= 1.2e-7 absolute) for |2^9 p| <= 2^20, i.e. |p| <= 2048 per coordinate -- three orders of
+ * magnitude beyond the scene (|p| <= 2.42 in the lego frustum); beyond that the accuracy degrades gradually, nothing faults.
+ * n is limited to INT32_MAX minus one grid stride of tiles (~2.1e9 points); larger batches return NERF_ERR_INVALID. */
 int nerf_forward_batch(nerf_ctx *ctx, int which, const float *pts_soa /*3 x n*/, const float *dirs_aos /*n x 3*/,
                        size_t n, float *rgb_aos /*n x 3*/, float *sigma /*n*/);
 /* same with an explicit MLP arithmetic (NERF_MLP_F32 / NERF_MLP_BF16 / NERF_MLP_BF16X3) */
@@ -213,8 +217,11 @@ int nerf_stage_resample(nerf_ctx *ctx, size_t n_rays, int nc, int nf, float far_
 int nerf_stage_integrate(nerf_ctx *ctx, size_t n_rays, int n, float far_, const float *rgb_aos, const float *sigma,
                          const float *t, float *rgb_out, float *w_out);
 
-/* ABI version: bumped on any signature change. */
+/* ABI version: bumped on any signature or struct change (2: multi-GPU entry points, skip_dead, n_exec_* statistics). */
 int nerf_abi_version(void);
+/* sizeof(nerf_camera), sizeof(nerf_render_opts), sizeof(nerf_stats) as this library was built: lets a binding written in
+ * another language (the Rust `-sys` crate, ctypes) check its struct mirrors at start-up. */
+void nerf_abi_struct_sizes(size_t *camera, size_t *render_opts, size_t *stats);
 
 #ifdef __cplusplus
 }

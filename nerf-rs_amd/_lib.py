@@ -42,6 +42,7 @@ class CStats(C.Structure):
 # name -> (restype, argtypes); kept in sync with include/nerf_mi355x.h (tests/test_abi.py checks the header)
 PROTOTYPES = {
     "nerf_abi_version": (C.c_int, []),
+    "nerf_abi_struct_sizes": (None, [C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "nerf_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
     "nerf_destroy": (None, [C.c_void_p]),
     "nerf_last_error": (C.c_char_p, [C.c_void_p]),
@@ -113,6 +114,12 @@ def load_library():
             fn = getattr(L, name)  # AttributeError if the symbol is not exported
             fn.restype = res
             fn.argtypes = args
+        sizes = [C.c_size_t() for _ in range(3)]
+        L.nerf_abi_struct_sizes(*[C.byref(x) for x in sizes])
+        mine = (C.sizeof(CCamera), C.sizeof(COpts), C.sizeof(CStats))
+        if tuple(x.value for x in sizes) != mine:
+            raise ImportError(f"{path}: struct layouts {tuple(x.value for x in sizes)} differ from the ctypes mirrors {mine} "
+                              "(stale build? run __graft_entry__.build())")
         _LIB = L
     return _LIB
 

@@ -36,9 +36,14 @@ int read_tensor_dir(const std::string &dir, std::map<std::string, Tensor> &out, 
         const std::string path = dir + "/" + name + ".bin";
         FILE *f = fopen(path.c_str(), "rb");
         if (!f) { err = "read tensor: " + path; return NERF_ERR_IO; }
-        fseek(f, 0, SEEK_END);
-        const long sz = ftell(f);
-        fseek(f, 0, SEEK_SET);
+        // file size: a directory or special file named <name>.bin gives -1 / nonsense -- an I/O error, not a 2^62-element resize
+        long sz = -1;
+        if (fseek(f, 0, SEEK_END) == 0) sz = ftell(f);
+        if (sz < 0 || fseek(f, 0, SEEK_SET) != 0 || (unsigned long)sz > (1ul << 32)) {
+            fclose(f);
+            err = "read tensor: " + path;
+            return NERF_ERR_IO;
+        }
         t.data.resize((size_t)sz / 4); // chunks_exact(4)
         if (!t.data.empty() && fread(t.data.data(), 4, t.data.size(), f) != t.data.size()) {
             fclose(f);

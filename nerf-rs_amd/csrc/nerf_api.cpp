@@ -292,6 +292,12 @@ int nerfint::render_device(nerf_ctx *c, const nerf_camera *cam, const nerf_rende
     }
     recycle_render(c);
     recycle_dominant(c, 4096); // bound the backlog if the caller never queries
+    // If this render returns early (a launch failed), its dominant-kernel event pairs never reach c->dominant: hand them back
+    // to last_render's ownership so that the next recycle_render returns them to the pool.
+    struct RenderScope {
+        nerf_ctx *c; bool ok = false;
+        ~RenderScope() { if (!ok) for (auto &p : c->last_render) if (p.kind == 1) p.kind = 2; }
+    } scope{c};
     if (o->skip_empty && c->d_skip) HIP_TRY(c, hipMemsetAsync(c->d_skip, 0, sizeof(unsigned long long), st));
     const bool timing = true;
     RayGenArgs g = make_raygen(*cam, s);
@@ -397,6 +403,7 @@ int nerfint::render_device(nerf_ctx *c, const nerf_camera *cam, const nerf_rende
     // the dominant-kernel events also feed nerf_kernel_time_query (ownership: see recycle_render)
     for (const auto &p : c->last_render)
         if (p.kind == 1) c->dominant.push_back(p);
+    scope.ok = true;
     if (stats) {
         HIP_TRY(c, hipStreamSynchronize(st));
         memset(stats, 0, sizeof *stats);
@@ -451,13 +458,25 @@ int nerfint::render_device(nerf_ctx *c, const nerf_camera *cam, const nerf_rende
 // ================================================================================================
 // extern "C"
 // ================================================================================================
+// No C++ exception may cross the C ABI (a Rust caller would abort): every entry point that can allocate is a function-try-block.
+#define NERF_CATCH(c)                                                                                              \
+    catch (const std::bad_alloc &) { return fail((c), NERF_ERR_IO, "out of host memory"); }                         \
+    catch (const std::exception &e) { return fail((c), NERF_ERR_INVALID, std::string("internal error: ") + e.what()); } \
+    catch (...) { return fail((c), NERF_ERR_INVALID, "internal error"); }
+
 extern "C" {
 
 int nerf_abi_version(void) { return 2; }
 
+void nerf_abi_struct_sizes(size_t *camera, size_t *render_opts, size_t *stats) {
+    if (camera) *camera = sizeof(nerf_camera);
+    if (render_opts) *render_opts = sizeof(nerf_render_opts);
+    if (stats) *stats = sizeof(nerf_stats);
+}
+
 const char *nerf_last_error(const nerf_ctx *ctx) { return ctx ? ctx->err.c_str() : g_err.c_str(); }
 
-int nerf_create(int device_id, nerf_ctx **out) {
+int nerf_create(int device_id, nerf_ctx **out) try {
     if (!out) return fail(nullptr, NERF_ERR_INVALID, "out is NULL");
     *out = nullptr;
     int n = 0;
@@ -495,12 +514,12 @@ int nerf_create(int device_id, nerf_ctx **out) {
     hipError_t e3 = e2 == hipSuccess ? hipStreamCreate(&c->stream) : e2;
     if (e3 != hipSuccess) {
         const std::string m = std::string("context initialisation failed: ") + hipGetErrorString(e3);
-        delete c;
+        nerf_destroy(c); // frees whatever was allocated so far (counters, clock buffer, stream)
         return fail(nullptr, NERF_ERR_HIP, m);
     }
     *out = c;
     return NERF_OK;
-}
+} NERF_CATCH(nullptr)
 
 void nerf_destroy(nerf_ctx *c) {
     if (!c) return;
@@ -529,7 +548,7 @@ int nerf_device_info(const nerf_ctx *c, int *n_cus, char *arch_name, size_t len)
     return NERF_OK;
 }
 
-int nerf_load_network_dir(nerf_ctx *c, int which, const char *dir) {
+int nerf_load_network_dir(nerf_ctx *c, int which, const char *dir) try {
     if (!c) return fail(nullptr, NERF_ERR_INVALID, "ctx is NULL");
     if (which != NERF_NET_COARSE && which != NERF_NET_FINE) return fail(c, NERF_ERR_INVALID, "which must be NERF_NET_COARSE or NERF_NET_FINE");
     if (!dir) return fail(c, NERF_ERR_INVALID, "dir is NULL");
@@ -542,10 +561,10 @@ int nerf_load_network_dir(nerf_ctx *c, int which, const char *dir) {
     rc = assemble_net(params, hn, err);
     if (rc) return fail(c, rc, err);
     return upload_net(c, which, hn);
-}
+} NERF_CATCH(c)
 
 int nerf_load_network_tensors(nerf_ctx *c, int which, int n, const char *const *names, const int64_t *dims,
-                              const float *const *data) {
+                              const float *const *data) try {
     if (!c) return fail(nullptr, NERF_ERR_INVALID, "ctx is NULL");
     if (which != NERF_NET_COARSE && which != NERF_NET_FINE) return fail(c, NERF_ERR_INVALID, "which must be NERF_NET_COARSE or NERF_NET_FINE");
     if (n < 0 || (n > 0 && (!names || !dims || !data))) return fail(c, NERF_ERR_INVALID, "bad tensor table");
@@ -565,11 +584,11 @@ int nerf_load_network_tensors(nerf_ctx *c, int which, int n, const char *const *
     const int rc = assemble_net(params, hn, err);
     if (rc) return fail(c, rc, err);
     return upload_net(c, which, hn);
-}
+} NERF_CATCH(c)
 
 static const char kBlobMagic[8] = {'N', 'R', 'F', 'M', 'I', '3', '5', '5'};
 
-int nerf_pack_network_dir(const char *dir, const char *blob_path) {
+int nerf_pack_network_dir(const char *dir, const char *blob_path) try {
     if (!dir || !blob_path) return fail(nullptr, NERF_ERR_INVALID, "NULL argument");
     std::map<std::string, Tensor> params;
     std::string err;
@@ -587,9 +606,9 @@ int nerf_pack_network_dir(const char *dir, const char *blob_path) {
                     fwrite(ws.data(), 4, ws.size(), f) == ws.size() && fwrite(sm.data(), 4, sm.size(), f) == sm.size();
     fclose(f);
     return ok ? NERF_OK : fail(nullptr, NERF_ERR_IO, std::string("short write ") + blob_path);
-}
+} NERF_CATCH(nullptr)
 
-int nerf_load_network_blob(nerf_ctx *c, int which, const char *blob_path) {
+int nerf_load_network_blob(nerf_ctx *c, int which, const char *blob_path) try {
     if (!c) return fail(nullptr, NERF_ERR_INVALID, "ctx is NULL");
     if (which != NERF_NET_COARSE && which != NERF_NET_FINE) return fail(c, NERF_ERR_INVALID, "which must be NERF_NET_COARSE or NERF_NET_FINE");
     if (!blob_path) return fail(c, NERF_ERR_INVALID, "blob_path is NULL");
@@ -605,10 +624,10 @@ int nerf_load_network_blob(nerf_ctx *c, int which, const char *blob_path) {
     if (!ok) return fail(c, NERF_ERR_SHAPE, std::string("not a version-1 packed network blob for this build: ") + blob_path);
     const int rc = upload_packed(c, which, ws, sm);
     return rc ? rc : bf16_from_f32_stream(c, which, ws);
-}
+} NERF_CATCH(c)
 
 int nerf_camera_from_pose(const float c2w[12], float ref_h, float ref_w, float focal, float near_, float far_, int width,
-                          int height, nerf_camera *out) {
+                          int height, nerf_camera *out) try {
     if (!c2w || !out) return fail(nullptr, NERF_ERR_INVALID, "NULL argument");
     const float origin[3] = {c2w[3], c2w[7], c2w[11]};
     const float forward[3] = {-c2w[2], -c2w[6], -c2w[10]};
@@ -616,9 +635,9 @@ int nerf_camera_from_pose(const float c2w[12], float ref_h, float ref_w, float f
     const float hwf[3] = {ref_h, ref_w, focal};
     camera_from_values(near_, far_, origin, forward, up, hwf, width, height, out);
     return NERF_OK;
-}
+} NERF_CATCH(nullptr)
 
-int nerf_check_network_dir(const char *dir) {
+int nerf_check_network_dir(const char *dir) try {
     if (!dir) return fail(nullptr, NERF_ERR_INVALID, "dir is NULL");
     std::map<std::string, Tensor> params;
     std::string err;
@@ -628,16 +647,16 @@ int nerf_check_network_dir(const char *dir) {
     rc = assemble_net(params, hn, err);
     if (rc) return fail(nullptr, rc, err);
     return NERF_OK;
-}
+} NERF_CATCH(nullptr)
 
-int nerf_debug_split_bf16x3(const float *values, size_t n, uint16_t *parts) {
+int nerf_debug_split_bf16x3(const float *values, size_t n, uint16_t *parts) try {
     if ((!values || !parts) && n) return fail(nullptr, NERF_ERR_INVALID, "NULL argument");
     for (size_t i = 0; i < n; ++i) split_bf16x3(values[i], parts + 3 * i);
     return NERF_OK;
-}
+} NERF_CATCH(nullptr)
 
 int nerf_debug_pack_network_dir(const char *dir, float *wstream, size_t wstream_cap, float *small, size_t small_cap,
-                                size_t *wstream_len, size_t *small_len) {
+                                size_t *wstream_len, size_t *small_len) try {
     if (!dir) return fail(nullptr, NERF_ERR_INVALID, "dir is NULL");
     std::map<std::string, Tensor> params;
     std::string err;
@@ -653,15 +672,17 @@ int nerf_debug_pack_network_dir(const char *dir, float *wstream, size_t wstream_
     if (wstream) { if (wstream_cap < ws.size()) return fail(nullptr, NERF_ERR_INVALID, "wstream buffer too small"); memcpy(wstream, ws.data(), ws.size() * sizeof(float)); }
     if (small) { if (small_cap < sm.size()) return fail(nullptr, NERF_ERR_INVALID, "small buffer too small"); memcpy(small, sm.data(), sm.size() * sizeof(float)); }
     return NERF_OK;
-}
+} NERF_CATCH(nullptr)
 
 static int forward_device(nerf_ctx *c, int which, int dtype, const float *d_pts, const float *d_dirs, size_t n, float *d_rgb,
                           float *d_sigma, void *stream);
+// largest batch of nerf_forward_batch*: INT32_MAX minus (persistent workgroups + 1) tiles of the widest kernel (256 points)
+static size_t max_batch_points(int n_cus) { return (size_t)0x7fffffff - ((size_t)n_cus + 1) * 256; }
 
 int nerf_forward_batch_device(nerf_ctx *c, int which, const float *d_pts, const float *d_dirs, size_t n, float *d_rgb,
-                              float *d_sigma, void *stream) {
+                              float *d_sigma, void *stream) try {
     return forward_device(c, which, NERF_MLP_F32, d_pts, d_dirs, n, d_rgb, d_sigma, stream);
-}
+} NERF_CATCH(c)
 
 static int forward_device(nerf_ctx *c, int which, int dtype, const float *d_pts, const float *d_dirs, size_t n, float *d_rgb,
                           float *d_sigma, void *stream) {
@@ -669,7 +690,8 @@ static int forward_device(nerf_ctx *c, int which, int dtype, const float *d_pts,
     if (which != NERF_NET_COARSE && which != NERF_NET_FINE) return fail(c, NERF_ERR_INVALID, "which must be NERF_NET_COARSE or NERF_NET_FINE");
     if (n == 0) return NERF_OK; // src/network.rs:199-201
     if (!d_pts || !d_dirs || !d_rgb || !d_sigma) return fail(c, NERF_ERR_INVALID, "NULL buffer");
-    if (n > (size_t)0x7fffff00) return fail(c, NERF_ERR_INVALID, "batch too large (n must fit in int32)");
+    // the kernels index points in int32 and look one persistent-grid stride of tiles ahead (load_raw): keep that in range too
+    if (n > max_batch_points(c->n_cus)) return fail(c, NERF_ERR_INVALID, "batch too large (n plus one grid stride of tiles must fit in int32)");
     if (!c->net[which].loaded) return fail(c, NERF_ERR_STATE, "network not loaded");
     DeviceGuard dg(c->device);
     MlpArgs a{};
@@ -681,11 +703,11 @@ static int forward_device(nerf_ctx *c, int which, int dtype, const float *d_pts,
     return NERF_OK;
 }
 
-int nerf_forward_batch(nerf_ctx *c, int which, const float *pts, const float *dirs, size_t n, float *rgb, float *sigma) {
+int nerf_forward_batch(nerf_ctx *c, int which, const float *pts, const float *dirs, size_t n, float *rgb, float *sigma) try {
     return nerf_forward_batch_ex(c, which, NERF_MLP_F32, pts, dirs, n, rgb, sigma);
-}
+} NERF_CATCH(c)
 
-int nerf_forward_batch_ex(nerf_ctx *c, int which, int dtype, const float *pts, const float *dirs, size_t n, float *rgb, float *sigma) {
+int nerf_forward_batch_ex(nerf_ctx *c, int which, int dtype, const float *pts, const float *dirs, size_t n, float *rgb, float *sigma) try {
     if (!c) return fail(nullptr, NERF_ERR_INVALID, "ctx is NULL");
     if (n == 0) return NERF_OK;
     if (!pts || !dirs || !rgb || !sigma) return fail(c, NERF_ERR_INVALID, "NULL buffer");
@@ -700,16 +722,16 @@ int nerf_forward_batch_ex(nerf_ctx *c, int which, int dtype, const float *pts, c
     HIP_TRY(c, hipMemcpyAsync(sigma, d_sig, n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return NERF_OK;
-}
+} NERF_CATCH(c)
 
 int nerf_render_image_device(nerf_ctx *c, const nerf_camera *cam, const nerf_render_opts *opts, float *d_rgb_out,
-                             void *stream, nerf_stats *stats) {
+                             void *stream, nerf_stats *stats) try {
     if (!c) return fail(nullptr, NERF_ERR_INVALID, "ctx is NULL");
     DeviceGuard dg(c->device);
     return render_device(c, cam, opts, d_rgb_out, (hipStream_t)stream, stats);
-}
+} NERF_CATCH(c)
 
-int nerf_render_image(nerf_ctx *c, const nerf_camera *cam, const nerf_render_opts *opts, float *rgb_out, nerf_stats *stats) {
+int nerf_render_image(nerf_ctx *c, const nerf_camera *cam, const nerf_render_opts *opts, float *rgb_out, nerf_stats *stats) try {
     if (!c) return fail(nullptr, NERF_ERR_INVALID, "ctx is NULL");
     if (!rgb_out) return fail(c, NERF_ERR_INVALID, "output pointer is NULL");
     int rc;
@@ -725,9 +747,9 @@ int nerf_render_image(nerf_ctx *c, const nerf_camera *cam, const nerf_render_opt
     HIP_TRY(c, hipMemcpyAsync(rgb_out, c->d_out, bytes, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return NERF_OK;
-}
+} NERF_CATCH(c)
 
-int nerf_kernel_time_query(nerf_ctx *c, double *ms, uint64_t *points, uint32_t *n_launches, int reset) {
+int nerf_kernel_time_query(nerf_ctx *c, double *ms, uint64_t *points, uint32_t *n_launches, int reset) try {
     if (!c) return fail(nullptr, NERF_ERR_INVALID, "ctx is NULL");
     DeviceGuard dg(c->device);
     double tot = 0.0; uint64_t pts = 0; uint32_t nl = 0;
@@ -747,9 +769,9 @@ int nerf_kernel_time_query(nerf_ctx *c, double *ms, uint64_t *points, uint32_t *
         recycle_dominant(c, 0);
     }
     return NERF_OK;
-}
+} NERF_CATCH(c)
 
-int nerf_debug_shader_clock_mhz(nerf_ctx *c, double *mhz) {
+int nerf_debug_shader_clock_mhz(nerf_ctx *c, double *mhz) try {
     if (!c || !mhz) return fail(c, NERF_ERR_INVALID, "NULL argument");
     if (!c->d_clock || !c->clock_valid) return fail(c, NERF_ERR_STATE, "set NERF_DEBUG_CLOCK=1 before nerf_create and render a frame first");
     DeviceGuard dg(c->device);
@@ -762,35 +784,36 @@ int nerf_debug_shader_clock_mhz(nerf_ctx *c, double *mhz) {
     std::sort(f.begin(), f.end());
     *mhz = f[f.size() / 2];
     return NERF_OK;
-}
+} NERF_CATCH(c)
 
-int nerf_camera_from_json(const char *path, int width, int height, nerf_camera *out) {
+int nerf_camera_from_json(const char *path, int width, int height, nerf_camera *out) try {
     if (!path || !out) return fail(nullptr, NERF_ERR_INVALID, "NULL argument");
     std::string err;
     const int rc = camera_from_json(path, width, height, out, err);
     return rc ? fail(nullptr, rc, err) : NERF_OK;
-}
+} NERF_CATCH(nullptr)
 
 int nerf_camera_from_values(float near_, float far_, const float origin[3], const float forward[3], const float up[3],
-                            const float hwf[3], int width, int height, nerf_camera *out) {
+                            const float hwf[3], int width, int height, nerf_camera *out) try {
     if (!origin || !forward || !up || !hwf || !out) return fail(nullptr, NERF_ERR_INVALID, "NULL argument");
     camera_from_values(near_, far_, origin, forward, up, hwf, width, height, out);
     return NERF_OK;
-}
+} NERF_CATCH(nullptr)
 
-int nerf_save_ppm(const char *path, int width, int height, const float *rgb) {
+int nerf_save_ppm(const char *path, int width, int height, const float *rgb) try {
     if (!path || !rgb) return fail(nullptr, NERF_ERR_INVALID, "NULL argument");
     std::string err;
     const int rc = save_ppm(path, width, height, rgb, err);
     return rc ? fail(nullptr, rc, err) : NERF_OK;
-}
+} NERF_CATCH(nullptr)
 
 void nerf_quantize_rgb8(const float *rgb, size_t n_pixels, uint8_t *out) { quantize_rgb8(rgb, n_pixels, out); }
 
 void nerf_quantize_rgba8(const float *rgb, size_t n_pixels, uint8_t *out) {
-    std::vector<uint8_t> tmp(3 * n_pixels);
-    quantize_rgb8(rgb, n_pixels, tmp.data());
-    for (size_t i = 0; i < n_pixels; ++i) { out[4 * i] = tmp[3 * i]; out[4 * i + 1] = tmp[3 * i + 1]; out[4 * i + 2] = tmp[3 * i + 2]; out[4 * i + 3] = 255; }
+    for (size_t i = 0; i < n_pixels; ++i) { // no allocation: nothing here can throw across the ABI
+        quantize_rgb8(rgb + 3 * i, 1, out + 4 * i);
+        out[4 * i + 3] = 255;
+    }
 }
 
 // ---- stage entry points ------------------------------------------------------------------------------------
@@ -803,7 +826,7 @@ static int stage_rect(nerf_ctx *c, const nerf_camera *cam, int x0, int y0, int w
     return NERF_OK;
 }
 
-int nerf_stage_ray_dirs(nerf_ctx *c, const nerf_camera *cam, int x0, int y0, int w, int h, int normalize, float *out) {
+int nerf_stage_ray_dirs(nerf_ctx *c, const nerf_camera *cam, int x0, int y0, int w, int h, int normalize, float *out) try {
     if (!c) return fail(nullptr, NERF_ERR_INVALID, "ctx is NULL");
     if (!out) return fail(c, NERF_ERR_INVALID, "NULL buffer");
     DeviceGuard dg(c->device);
@@ -816,9 +839,9 @@ int nerf_stage_ray_dirs(nerf_ctx *c, const nerf_camera *cam, int x0, int y0, int
     HIP_TRY(c, hipMemcpyAsync(out, c->d_scratch, bytes, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return NERF_OK;
-}
+} NERF_CATCH(c)
 
-int nerf_stage_stratified(nerf_ctx *c, const nerf_camera *cam, int x0, int y0, int w, int h, int count, uint64_t seed, float *out) {
+int nerf_stage_stratified(nerf_ctx *c, const nerf_camera *cam, int x0, int y0, int w, int h, int count, uint64_t seed, float *out) try {
     if (!c) return fail(nullptr, NERF_ERR_INVALID, "ctx is NULL");
     if (!out) return fail(c, NERF_ERR_INVALID, "NULL buffer");
     if (count <= 0) return NERF_OK; // src/lib.rs:235-237
@@ -831,11 +854,11 @@ int nerf_stage_stratified(nerf_ctx *c, const nerf_camera *cam, int x0, int y0, i
     HIP_TRY(c, hipMemcpyAsync(out, c->d_scratch, bytes, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return NERF_OK;
-}
+} NERF_CATCH(c)
 
 int nerf_stage_resample(nerf_ctx *c, size_t n_rays, int nc, int nf, float far_, uint64_t seed, const uint32_t *pixel_index,
                         const float *t_coarse, const float *sigma_coarse, const float *u, float *w_out, float *cdf_out,
-                        float *t_new_out, float *t_fine_out) {
+                        float *t_new_out, float *t_fine_out) try {
     if (!c) return fail(nullptr, NERF_ERR_INVALID, "ctx is NULL");
     if (n_rays == 0) return NERF_OK;
     if (!t_coarse || !sigma_coarse || !t_fine_out) return fail(c, NERF_ERR_INVALID, "NULL buffer");
@@ -869,10 +892,10 @@ int nerf_stage_resample(nerf_ctx *c, size_t n_rays, int nc, int nf, float far_, 
     HIP_TRY(c, hipMemcpyAsync(t_fine_out, d + o_tf, R * M * 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return NERF_OK;
-}
+} NERF_CATCH(c)
 
 int nerf_stage_integrate(nerf_ctx *c, size_t n_rays, int n, float far_, const float *rgb, const float *sigma, const float *t,
-                         float *rgb_out, float *w_out) {
+                         float *rgb_out, float *w_out) try {
     if (!c) return fail(nullptr, NERF_ERR_INVALID, "ctx is NULL");
     if (n_rays == 0) return NERF_OK;
     if (!rgb_out) return fail(c, NERF_ERR_INVALID, "NULL buffer");
@@ -895,6 +918,6 @@ int nerf_stage_integrate(nerf_ctx *c, size_t n_rays, int n, float far_, const fl
     if (w_out) HIP_TRY(c, hipMemcpyAsync(w_out, d + o_w, R * N * 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return NERF_OK;
-}
+} NERF_CATCH(c)
 
 } // extern "C"

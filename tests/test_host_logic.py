@@ -286,3 +286,57 @@ def test_bf16x3_split_is_exact_to_2pow27_and_six_products_match_f32(native):
     six = (w[:, 2] * x[:, 0] + w[:, 1] * x[:, 1] + w[:, 0] * x[:, 2]) + (w[:, 1] * x[:, 0] + w[:, 0] * x[:, 1]) + w[:, 0] * x[:, 0]
     exact = v[:12000].astype(np.float64) * v[12000:24000].astype(np.float64)
     assert (np.abs(six - exact) <= 2.0 ** -24 * np.abs(exact) + 1e-40).all()          # within half an f32 ulp of the true product
+
+
+def _c_prototypes(text):
+    """name -> number of parameters, for every function declared in a C header (comments stripped)."""
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    out = {}
+    for name, args in re.findall(r"\b(nerf_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", text, flags=re.S):
+        args = args.strip()
+        out[name] = 0 if args in ("", "void") else len(args.split(","))
+    return out
+
+
+def test_rust_sys_crate_declares_the_whole_header():
+    """bindings/rust/nerf-mi355x-sys cannot be compiled here (no rustc in the image), so its `extern "C"` block is checked
+    textually against include/nerf_mi355x.h: same function names, same number of arguments; and the #[repr(C)] struct mirrors
+    list the same number of fields as the ctypes mirrors (whose sizes the library verifies at load time)."""
+    from nerf_rs_amd import _lib
+    header = _c_prototypes(open(HEADER).read())
+    rs = open(os.path.join(ROOT, "bindings", "rust", "nerf-mi355x-sys", "src", "lib.rs")).read()
+    rs_nc = re.sub(r"//.*", "", rs)
+    block = rs_nc[rs_nc.index('extern "C" {'):]
+    block = block[:block.index("\n}")]
+    rust = {}
+    for name, args in re.findall(r"pub fn (nerf_[a-z0-9_]+)\s*\(([^)]*)\)", block, flags=re.S):
+        rust[name] = len([a for a in args.split(",") if a.strip()])
+    assert set(rust) == set(header), (sorted(set(header) - set(rust)), sorted(set(rust) - set(header)))
+    assert rust == header
+    assert set(header) == set(_lib.PROTOTYPES) and all(len(_lib.PROTOTYPES[n][1]) == header[n] for n in header)
+    for struct, mirror in (("nerf_camera", _lib.CCamera), ("nerf_render_opts", _lib.COpts), ("nerf_stats", _lib.CStats)):
+        body = rs_nc[rs_nc.index(f"pub struct {struct} {{"):]
+        body = body[:body.index("}")]
+        fields = re.findall(r"pub ([a-z_0-9]+):", body)
+        assert fields == [f[0] for f in mirror._fields_], (struct, fields)
+    # the same functions in INTEGRATION.md's extern block (what a maintainer of the reference would paste)
+    integ = re.sub(r"//.*", "", open(os.path.join(ROOT, "INTEGRATION.md")).read())
+    integ_fns = set(re.findall(r"pub fn (nerf_[a-z0-9_]+)\s*\(", integ))
+    assert integ_fns <= set(header) and {"nerf_create", "nerf_render_image", "nerf_render_image_multi", "nerf_forward_batch"} <= integ_fns
+
+
+def test_struct_sizes_match_the_library(native):
+    from nerf_rs_amd import _lib
+    L = native.load_library()
+    a, b, c = C.c_size_t(), C.c_size_t(), C.c_size_t()
+    L.nerf_abi_struct_sizes(C.byref(a), C.byref(b), C.byref(c))
+    assert (a.value, b.value, c.value) == (C.sizeof(_lib.CCamera), C.sizeof(_lib.COpts), C.sizeof(_lib.CStats)) == (60, 56, 96)
+
+
+def test_loader_rejects_a_directory_named_like_a_tensor(native, tmp_path):
+    """A <name>.bin that is a directory (ftell gives -1 or nonsense) must be an I/O error, not a giant allocation or an
+    exception across the C ABI."""
+    d = tmp_path / "net"; shutil.copytree(os.path.join(SCENE, "coarse"), d)
+    os.remove(d / "dense2_bias.bin"); os.mkdir(d / "dense2_bias.bin")
+    rc, msg = _check(native, d)
+    assert rc == -2 and "read tensor" in msg and "dense2_bias" in msg
