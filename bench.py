@@ -149,6 +149,9 @@ def main():
                     help="MLP arithmetic: f32 = BASELINE's headline config (C3, default, f32 MFMA); bf16 = the C5 study (not the headline); "
                          "bf16x3 = f32-accurate three-way bf16 split on the bf16 matrix cores (opt-in, meets the f32 tolerances)")
     ap.add_argument("--ssaa", type=int, default=1, help="s x s rays per pixel (C5: --dtype bf16 --ssaa 2)")
+    ap.add_argument("--skip-dead", action="store_true",
+                    help="SURVEY 8f.2 (reported separately, not the headline): exact dead-sample skipping as the timed path (profiling runs); "
+                         "the roofline line is then the ray-sequential trunk kernel priced in EXECUTED flops")
     ap.add_argument("--skip-empty", action="store_true",
                     help="SURVEY 8f.2 (reported separately, not the headline): skip the colour head of all-empty tiles; "
                          "the image is bit-identical, the roofline line then prices EXECUTED flops")
@@ -204,10 +207,10 @@ def main():
     def step():
         if not use_dist or weak:
             N.render_image(r.coarse, r.fine, cam, args.fine, seed=view_seed, ssaa=args.ssaa, dtype=args.dtype,
-                           skip_empty=args.skip_empty, device_out=frame.data_ptr(), stream=stream)
+                           skip_empty=args.skip_empty, skip_dead=args.skip_dead, device_out=frame.data_ptr(), stream=stream)
             return frame
         return N.render_image_distributed(r.coarse, r.fine, cam, args.fine, seed=args.seed, ssaa=args.ssaa, dtype=args.dtype,
-                                          skip_empty=args.skip_empty, return_tensor=True)
+                                          skip_empty=args.skip_empty, skip_dead=args.skip_dead, return_tensor=True)
 
     def fence():
         if use_dist:
@@ -230,9 +233,14 @@ def main():
                             skip_empty=True, device_out=frame.data_ptr(), stream=stream, return_stats=True)
         skipped_per_launch = st.n_colour_skipped_points
         r.kernel_time_query(reset=True)
+    dead_stats = None
+    if args.skip_dead and world == 1:  # one extra untimed frame with stats: the executed-work counts are deterministic per frame
+        dead_stats = N.render_image(r.coarse, r.fine, cam, args.fine, seed=args.seed, ssaa=args.ssaa, dtype=args.dtype, skip_dead=True,
+                                    device_out=frame.data_ptr(), stream=stream, return_stats=True)
+        r.kernel_time_query(reset=True)
     # Reported separately, never part of `value`: the same frame with exact empty-tile skipping.
     extra_skip = None
-    if world == 1 and not args.skip_empty and not args.no_extra:
+    if world == 1 and not args.skip_empty and not args.skip_dead and not args.no_extra:
         def skip_step():
             N.render_image(r.coarse, r.fine, cam, args.fine, seed=args.seed, ssaa=args.ssaa, dtype=args.dtype, skip_empty=True,
                            device_out=frame.data_ptr(), stream=stream)
@@ -248,9 +256,42 @@ def main():
                       "image_bit_identical_to_headline_run": identical,
                       "note": "opt-in skip_empty: colour head skipped for workgroup tiles (128 samples f32, 256 bf16) whose densities are all 0 (exact)"}
         r.kernel_time_query(reset=True)
+    # Reported separately (the rest of it), never part of `value`: the same frame with exact dead-sample skipping --
+    # rays retired at the reference's T < 1e-4 cut, colour head only on samples with weight > 0 -- priced in EXECUTED flops.
+    extra_dead = None
+    if world == 1 and args.dtype == "f32" and not args.skip_empty and not args.skip_dead and not args.no_extra:
+        def dead_step(stats=False):
+            return N.render_image(r.coarse, r.fine, cam, args.fine, seed=args.seed, ssaa=args.ssaa, skip_dead=True,
+                                  device_out=frame.data_ptr(), stream=stream, return_stats=stats)
+        step(); torch.cuda.synchronize(dev)
+        ref_frame = frame.clone()
+        st = dead_step(stats=True); torch.cuda.synchronize(dev)
+        identical = bool(torch.equal(frame, ref_frame))
+        t1 = time.perf_counter()
+        for _ in range(3):
+            dead_step()
+        torch.cuda.synchronize(dev)
+        ms = 1e3 * (time.perf_counter() - t1) / 3
+        exec_flop = ((st.n_exec_coarse_trunk + st.n_exec_fine_trunk) * N.FLOP_PER_POINT_SIGMA +
+                     st.n_exec_colour * (N.FLOP_PER_POINT_FULL - N.FLOP_PER_POINT_SIGMA))
+        n_r = args.width * args.height * args.ssaa * args.ssaa
+        extra_dead = {"rays_per_s": n_r / (ms * 1e-3), "ms_per_step": ms, "image_bit_identical_to_headline_run": identical,
+                      "executed_fraction_coarse_trunk": st.n_exec_coarse_trunk / max(st.n_coarse_points, 1),
+                      "executed_fraction_fine_trunk": st.n_exec_fine_trunk / max(st.n_fine_points, 1),
+                      "executed_fraction_colour_head": st.n_exec_colour / max(st.n_fine_points, 1),
+                      "executed_flop_per_frame": exec_flop, "algorithmic_flop_per_frame": n_r * N.flop_per_ray(args.coarse, args.fine),
+                      "executed_tflops": exec_flop / (ms * 1e-3) / 1e12,
+                      "executed_fraction_of_fp32_mfma_roofline": exec_flop / (ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+                      "device_ms": {"total": st.ms_total, "coarse_trunk": st.ms_coarse_mlp, "fine_trunk_plus_colour": st.ms_fine_mlp,
+                                    "other": st.ms_other, "passes": st.n_passes},
+                      "note": "opt-in skip_dead (exact): ray-sequential trunk kernel walks each ray front to back in 32-sample chunks off a "
+                              "device-side ray queue and retires it at the reference's T < 1e-4 cut (src/lib.rs:276-279); samples with "
+                              "weight > 0 export the trunk output (1 KiB) to a compacted buffer, a second launch runs bottleneck + viewdirs + "
+                              "rgb on those only"}
+        r.kernel_time_query(reset=True)
     # Reported separately, never part of `value`: the same frame in the opt-in f32-accurate bf16x3 arithmetic.
     extra_x3 = None
-    if world == 1 and args.dtype == "f32" and not args.skip_empty and not args.no_extra:
+    if world == 1 and args.dtype == "f32" and not args.skip_empty and not args.skip_dead and not args.no_extra:
         def x3_step():
             N.render_image(r.coarse, r.fine, cam, args.fine, seed=args.seed, ssaa=args.ssaa, dtype="bf16x3",
                            device_out=frame.data_ptr(), stream=stream)
@@ -268,9 +309,10 @@ def main():
                     "max_abs_diff_vs_f32_frame": float(diff.max().item()), "mean_abs_diff_vs_f32_frame": float(diff.mean().item()),
                     "fraction_of_values_differing_by_more_than_5e-5": float((diff > 5e-5).float().mean().item()),
                     "psnr_vs_f32_frame_db": float(-10.0 * torch.log10((diff.double() ** 2).mean().clamp_min(1e-30)).item()),
-                    "note": "opt-in mlp_dtype bf16x3: every f32 product as the six significant bf16 x bf16 products of three-way splits, "
-                            "f32 accumulate; passes the f32 path's tolerances against the oracle (tests/test_gpu_parity.py); the few values "
-                            "above 5e-5 are pixels where a coarse-density difference of 1e-5 relocates one fine sample (DESIGN 6, parity row)"}
+                    "note": "opt-in mlp_dtype bf16x3: the fine (colour) pass computes every f32 product as the six significant bf16 x bf16 "
+                            "products of three-way splits, f32 accumulate; the coarse (sampling) pass stays on the f32 MFMA kernel, so the "
+                            "fine sample positions equal the f32 path's bit for bit; passes the UNRELAXED Gate 1 against the oracle "
+                            "(tests/test_gpu_parity.py::test_bf16x3_render_matches_oracle_crop, tests/test_gpu_fullframe.py)"}
         r.kernel_time_query(reset=True)
     # The timed region leaves the frame in HBM (`value` never includes PCIe); the host-pointer entry point additionally pays
     # one D2H copy of the frame (BASELINE.md section 4 counts it on the GPU side): measured here, reported beside `value`.
@@ -298,9 +340,12 @@ def main():
         value = n_rays * args.steps * (world if weak else 1) / dt  # whole-job rays/s over all ranks
         # executed flops of the dominant launches: a skipped sample still runs dense0..7 + alpha (sigma-only cost)
         flops_dom = pts_dom * N.FLOP_PER_POINT_FULL - n_dom * skipped_per_launch * (N.FLOP_PER_POINT_FULL - N.FLOP_PER_POINT_SIGMA)
+        if dead_stats is not None:  # dominant launch = the ray-sequential fine trunk (dense0..7 + alpha on the samples in front of the cut)
+            flops_dom = n_dom * dead_stats.n_exec_fine_trunk * N.FLOP_PER_POINT_SIGMA
         ach = mfma_per_flop * flops_dom / (ms_dom * 1e-3) / 1e12 if ms_dom > 0 else 0.0
         traffic, traffic_src = pmc_traffic_bytes("void nerf_mlp_kernel_bf16v2<true" if bf16 else
-                                                 "void nerf_mlp_kernel_bf16x3<true" if x3 else "void nerf_mlp_kernel<true")
+                                                 "void nerf_mlp_kernel_bf16x3<true" if x3 else
+                                                 "void nerf_trunk_seq_kernel<true" if args.skip_dead else "void nerf_mlp_kernel<true")
         line = {  # noqa: E501
             "metric": "rays/sec, lego 800x800 (64 coarse + 128 fine samples per ray)", "value": value, "unit": "rays/s",
             "n_gpus": world, "ranks": dist.get_world_size() if use_dist else 1,
@@ -321,14 +366,16 @@ def main():
                        "frame": "left in HBM inside the timed region (value excludes PCIe)",
                        "d2h_ms_per_frame": d2h_ms,
                        "rays_per_s_including_d2h": (n_rays / (dt / args.steps + 1e-3 * d2h_ms)) if d2h_ms is not None else None,
-                       "skip_empty": bool(args.skip_empty), "colour_head_skipped_samples_per_frame": skipped_per_launch,
+                       "skip_empty": bool(args.skip_empty), "skip_dead": bool(args.skip_dead),
+                       "colour_head_skipped_samples_per_frame": skipped_per_launch,
                        "whole_job_fraction_of_mfma_roofline": mfma_per_flop * value * flop_ray / (world * peak * 1e12)},  # per-GPU average
             "roofline": {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
                          "frac": ach / peak, "traffic": traffic,
                          "traffic_source": (f"HBM bytes per launch from the committed rocprofv3 PMC passes ({traffic_src}; 2 x FETCH_SIZE + WRITE_SIZE "
                                             "in separate --pmc runs), not re-measured in this run; algorithmic: 20 B/point") if traffic_src else None,
-                         "kernel": ("nerf_mlp_kernel_bf16v2" if bf16
-                                    else "nerf_mlp_kernel_bf16x3" if x3 else "nerf_mlp_kernel") + "<FULL=true, MODE_RAYS> (fine network)",
+                         "kernel": ("nerf_trunk_seq_kernel<EXPORT=true> (fine network, ray-sequential trunk; executed flops)" if dead_stats is not None else
+                                    ("nerf_mlp_kernel_bf16v2" if bf16 else "nerf_mlp_kernel_bf16x3" if x3 else "nerf_mlp_kernel") +
+                                    "<FULL=true, MODE_RAYS> (fine network)"),
                          "launches": n_dom, "avg_launch_ms": ms_dom / max(n_dom, 1),
                          "points_per_launch": pts_dom // max(n_dom, 1), "flop_per_point": N.FLOP_PER_POINT_FULL},
         }
@@ -340,6 +387,8 @@ def main():
             line["extra_bf16x3"] = extra_x3
         if extra_skip:
             line["extra_skip_empty"] = extra_skip
+        if extra_dead:
+            line["extra_skip_dead"] = extra_dead
         if world == 1 and not args.no_cpu_baseline and not bf16 and not x3:
             line["cpu_baseline"] = cpu_baseline(args.width, args.height, args.coarse, args.fine, args.seed, not args.no_cpu_reference_order)
         print(json.dumps(line), flush=True)

@@ -335,6 +335,7 @@ def test_packed_blob_loads_identically(renderer, native, tmp_path):
             ref = (renderer.coarse if which == 0 else renderer.fine).forward_batch(g["pts"], g["dirs"])
             out = net.forward_batch(g["pts"], g["dirs"])
             assert np.array_equal(out[0], ref[0]) and np.array_equal(out[1], ref[1])
+            _close_mlp(out[0], out[1], g[f"{sub}_rgb"], g[f"{sub}_sigma"])   # and against the oracle's fixture, not only HIP vs HIP
             for dt in ("bf16", "bf16x3"):   # the bf16-family streams are rebuilt from the blob's f32 stream: same bits as from the directory
                 ref_d = (renderer.coarse if which == 0 else renderer.fine).forward_batch(g["pts"], g["dirs"], dtype=dt)
                 out_d = net.forward_batch(g["pts"], g["dirs"], dtype=dt)
@@ -357,9 +358,11 @@ def test_c2_full_frame_coarse_only_400(renderer, native, samples):
     assert st.n_rays == 160000 and st.n_coarse_points == 160000 * 64 and st.n_fine_points == 0
 
 
-def test_multi_view_frame_loop(renderer, native, samples):
+def test_multi_view_frame_loop(renderer, native, oracle, oracle_nets, samples):
     """Persistent device state across frames with different poses: rotating the camera about the scene's
-    up axis gives a different, still valid image; returning to the first pose reproduces it bit-for-bit."""
+    up axis gives a different, still valid image; returning to the first pose reproduces it bit-for-bit; and the frame at the
+    40-degree pose passes Gate 1 against the oracle rendering the same pose (nerf_camera_from_pose vs camera_from_samples'
+    origin / forward / up convention, src/lib.rs:614-645)."""
     c2w = np.array(samples["camera_matrix"], np.float64)
     def pose(deg):
         a = np.deg2rad(deg); R = np.array([[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1]])
@@ -371,6 +374,11 @@ def test_multi_view_frame_loop(renderer, native, samples):
     assert np.array_equal(imgs[0], imgs[3]) and not np.array_equal(imgs[0], imgs[1])
     for im in imgs:
         assert np.isfinite(im).all() and 0.3 < np.all(im == 1.0, axis=2).mean() < 0.95 and im.min() < 0.5
+    m = pose(40)
+    rotated = dict(samples, camera_origin=list(m[:, 3]), camera_forward=list(-m[:, 2]), camera_up=list(m[:, 1]))
+    ref = oracle.render_image(*oracle_nets, oracle.camera_from_samples(rotated, 96, 96), oracle.make_opts(64, 128, seed=0))
+    _gate1(imgs[1], ref)
+    _gate1(imgs[0], oracle.render_image(*oracle_nets, oracle.camera_from_samples(samples, 96, 96), oracle.make_opts(64, 128, seed=0)))
 
 
 # ---- bf16 MLP (BASELINE config C5): PSNR-level parity only, arithmetic checked against the oracle's bf16 emulation ------
@@ -487,6 +495,8 @@ def test_skip_empty_is_bit_exact(renderer, native, samples):
     ref = native.render_image(renderer.coarse, renderer.fine, cam, 128, seed=0, crop=crop)
     img, st = native.render_image(renderer.coarse, renderer.fine, cam, 128, seed=0, crop=crop, skip_empty=True, return_stats=True)
     assert np.array_equal(img, ref)
+    g = golden("crop_c3_800_64_128.npz")                       # and against the oracle's fixture, not only HIP vs HIP
+    _gate1(native.render_image(renderer.coarse, renderer.fine, cam, 128, seed=0, crop=tuple(int(v) for v in g["crop"]), skip_empty=True), g["image"])
     assert 0.2 * st.n_fine_points < st.n_colour_skipped_points < st.n_fine_points   # it really skipped a lot, not everything
     assert st.n_colour_skipped_points % 128 == 0
     cam4 = native.camera_from_samples(samples, 400, 400, 64)
@@ -632,3 +642,23 @@ def test_gpu_f32_is_as_accurate_as_the_reference_arithmetic(renderer, oracle_net
         print(f"\n{sub}: error vs float64 (sigma rel, rgb abs)  f32 MFMA {gs:.2e} {gr:.2e} | bf16x3 {xs:.2e} {xr:.2e} | CPU reference arithmetic {os_:.2e} {or_:.2e}")
         assert xs <= 3e-5 and xr <= 8e-6, (xs, xr)
         assert xs <= 2.0 * os_ + 2e-6 and xr <= 2.0 * or_ + 5e-7, ((xs, xr), (os_, or_))
+
+
+def test_forward_batch_input_domain_and_batch_cap(renderer, native, oracle_nets):
+    """include/nerf_mi355x.h documents |p| <= 2048 per coordinate for nerf_forward_batch (the branch-free sin/cos reduction is
+    accurate to 1.2e-7 for |2^9 p| <= 2^20): points far outside the scene must still match the oracle (libm sinf/cosf) at the
+    f32 tolerances.  And a batch whose look-ahead tile index would leave int32 is refused, not launched."""
+    rng = np.random.default_rng(7)
+    n = 8192
+    v = rng.normal(size=(n, 3)); dirs = (v / np.linalg.norm(v, axis=1, keepdims=True)).astype(np.float32)
+    for span in (64.0, 2000.0):
+        pts = rng.uniform(-span, span, size=(3, n)).astype(np.float32)
+        rgb, sg = renderer.fine.forward_batch(pts, dirs)
+        ergb, esg = oracle_nets[1].forward_batch(pts, dirs)
+        ds = np.abs(sg - esg) / (1 + np.abs(esg))
+        print(f"\n|p| <= {span:g}: sigma rel err max {ds.max():.2e}, rgb abs err max {np.abs(rgb - ergb).max():.2e}, sigma max {esg.max():.0f}")
+        assert np.isfinite(sg).all() and np.isfinite(rgb).all()
+        assert ds.max() <= 3e-4 and np.abs(rgb - ergb).max() <= 1e-4      # activations grow with |p|: a few f32 ulps more than in the scene
+    L = native.load_library()
+    rc = L.nerf_forward_batch_device(renderer.handle, 1, 0x1000, 0x1000, (1 << 31) - 300, 0x1000, 0x1000, None)   # never dereferenced
+    assert rc == -1 and b"batch too large" in L.nerf_last_error(renderer.handle)
