@@ -341,7 +341,7 @@ def main():
         # executed flops of the dominant launches: a skipped sample still runs dense0..7 + alpha (sigma-only cost)
         flops_dom = pts_dom * N.FLOP_PER_POINT_FULL - n_dom * skipped_per_launch * (N.FLOP_PER_POINT_FULL - N.FLOP_PER_POINT_SIGMA)
         if dead_stats is not None:  # dominant launch = the ray-sequential fine trunk (dense0..7 + alpha on the samples in front of the cut)
-            flops_dom = n_dom * dead_stats.n_exec_fine_trunk * N.FLOP_PER_POINT_SIGMA
+            flops_dom = (n_dom / max(dead_stats.n_passes, 1)) * dead_stats.n_exec_fine_trunk * N.FLOP_PER_POINT_SIGMA  # one launch per pass
         ach = mfma_per_flop * flops_dom / (ms_dom * 1e-3) / 1e12 if ms_dom > 0 else 0.0
         traffic, traffic_src = pmc_traffic_bytes("void nerf_mlp_kernel_bf16v2<true" if bf16 else
                                                  "void nerf_mlp_kernel_bf16x3<true" if x3 else
@@ -377,7 +377,8 @@ def main():
                                     ("nerf_mlp_kernel_bf16v2" if bf16 else "nerf_mlp_kernel_bf16x3" if x3 else "nerf_mlp_kernel") +
                                     "<FULL=true, MODE_RAYS> (fine network)"),
                          "launches": n_dom, "avg_launch_ms": ms_dom / max(n_dom, 1),
-                         "points_per_launch": pts_dom // max(n_dom, 1), "flop_per_point": N.FLOP_PER_POINT_FULL},
+                         "points_per_launch": pts_dom // max(n_dom, 1),
+                         "flop_per_point": N.FLOP_PER_POINT_SIGMA if dead_stats is not None else N.FLOP_PER_POINT_FULL},
         }
         if x3:
             line["roofline"]["note"] = ("achieved/peak price the EXECUTED bf16 MFMA flops (6 per algorithmic f32 flop) against the bf16 peak; "

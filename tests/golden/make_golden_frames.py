@@ -2,7 +2,7 @@
 """Whole-frame fixtures from the CPU oracle (oracle/nerf_oracle.c) for the GPU suite, which cannot run the oracle at
 this size (the GPU box has no /root/reference and the -m gpu suite must stay short).
 
-    python tests/golden/make_golden_frames.py [threads]     # ~45 min on 8 cores; rewrites the two files below
+    python tests/golden/make_golden_frames.py [threads]     # ~20 min on 16 fast cores, hours on 8 slow ones; rewrites the two files below
 
   frame_c3_800_seed0.npz   BASELINE config C3 (lego 800x800, 64 + 128 samples/ray, f32), seed 0: the oracle's whole frame
                            (`image`, 800 x 800 x 3 f32 linear RGB) and its save_ppm quantisation (`rgb8`, src/lib.rs:573-577)
@@ -25,7 +25,7 @@ sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import oracle_py as O  # noqa: E402
 
 SCENE = os.path.join(ROOT, "lego_rust")
-OUT = os.path.join(ROOT, "tests", "golden")
+OUT = os.environ.get("NERF_GOLDEN_OUT") or os.path.join(ROOT, "tests", "golden")  # NERF_GOLDEN_OUT: write elsewhere (e.g. gpurun_out/)
 
 
 def psnr(a, b):
@@ -33,13 +33,26 @@ def psnr(a, b):
     return 10.0 * np.log10(1.0 / mse)
 
 
+def heartbeat(t0):
+    """A progress line per minute (a silent 12-minute SSAA frame looks hung to a job runner)."""
+    import threading
+
+    def beat():
+        while True:
+            time.sleep(60)
+            print("  ... %.0f s" % (time.time() - t0), flush=True)
+    threading.Thread(target=beat, daemon=True).start()
+
+
 def main():
     threads = int(sys.argv[1]) if len(sys.argv) > 1 else len(os.sched_getaffinity(0))
+    os.makedirs(OUT, exist_ok=True)
     S = O.load_samples(os.path.join(SCENE, "tf_reference_samples.json"))
     co, fi = O.Net(os.path.join(SCENE, "coarse")), O.Net(os.path.join(SCENE, "fine"))
     cam = O.camera_from_samples(S, 800, 800)
     gates = {"config": "lego 800x800, 64 + 128 samples/ray, f32 oracle; A = seed-0 frame (frame_c3_800_seed0.npz)"}
     t0 = time.time()
+    heartbeat(t0)
     a = O.render_image(co, fi, cam, O.make_opts(64, 128, seed=0, threads=threads))
     gates["oracle_seconds_seed0"] = round(time.time() - t0, 1); gates["oracle_threads"] = threads
     np.savez_compressed(os.path.join(OUT, "frame_c3_800_seed0.npz"), image=a, rgb8=O.quantize_rgb8(a), seed=np.uint64(0),

@@ -32,7 +32,7 @@ lines = [f"# rocprofv3 summary {tag}", "", "Command: `rocprofv3 --kernel-trace -
          "separate `--pmc` passes (`bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extra" + (" " + extra if extra else "") + "`), MI355X, 800x800, 64+128 samples.", "", "## kernel-trace stats", "", "```"]
 lines += open(os.path.join(dst, f"{tag}_kernel_stats.csv")).read().strip().split("\n") + ["```", "", "## derived (PMC pass, one frame)", ""]
 for k, v in agg.items():
-    if "nerf_mlp_kernel" not in k or not v.get("SQ_VALU_MFMA_BUSY_CYCLES"):
+    if not any(n in k for n in ("nerf_mlp_kernel", "nerf_trunk_seq_kernel", "nerf_colour_kernel")) or not v.get("SQ_VALU_MFMA_BUSY_CYCLES"):
         continue
     t = dur[k] * 1e-3
     clk = v["GRBM_GUI_ACTIVE"] / 8 / t / 1e9
