@@ -29,10 +29,10 @@ def pmc_traffic_bytes(kernel_prefix="void nerf_mlp_kernel<true"):
     """HBM bytes per launch of the fine-MLP kernel from the committed rocprofv3 PMC passes (profiles/*_pmc_summary.csv:
     separate FETCH_SIZE / WRITE_SIZE runs; FETCH_SIZE doubled per the gfx950 note in MI355X_MICROARCH.md).  The kernel is
     MFMA-bound; this is reported for completeness (algorithmic: 20 B/point in+out = 2.46 GB per 122.88 M-point launch).
-    The newest summary that holds the kernel wins."""
+    The summary of the latest round (by file name) that holds the kernel wins."""
     import csv
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.csv")), key=os.path.getmtime, reverse=True)
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.csv")), reverse=True)  # r02_* before r01_*: newest round first
     for f in files:
         for row in csv.DictReader(open(f)):
             if row["kernel"].startswith(kernel_prefix) and float(row.get("FETCH_SIZE", 0) or 0) > 0:
