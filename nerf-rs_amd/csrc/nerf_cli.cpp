@@ -16,7 +16,8 @@
 static void usage(const char *argv0) {
     fprintf(stderr,
             "usage: %s [--scene DIR] [--width W] [--height H] [--coarse N] [--fine N] [--seed S] [--ssaa S]\n"
-            "          [--coarse-only] [--crop X0,Y0,W,H] [--dtype f32|bf16|bf16x3] [--device ID] [--frames K] [--out FILE.ppm]\n"
+            "          [--coarse-only] [--crop X0,Y0,W,H] [--dtype f32|bf16|bf16x3] [--skip-empty] [--skip-dead]\n"
+            "          [--device ID | --gpus N | --devices ID,ID,... [--gather host|peer|rccl]] [--frames K] [--out FILE.ppm]\n"
             "defaults: --scene lego_rust --width 256 --height 256 --coarse 64 --fine 128 --out output.ppm\n",
             argv0);
 }
@@ -24,7 +25,8 @@ static void usage(const char *argv0) {
 int main(int argc, char **argv) {
     std::string scene = getenv("NERF_SCENE_DIR") ? getenv("NERF_SCENE_DIR") : "lego_rust";
     std::string out = "output.ppm";
-    int width = 256, height = 256, device = 0, frames = 1; // src/lib.rs:657-658
+    int width = 256, height = 256, device = 0, frames = 1, gpus = 1, gather = NERF_GATHER_HOST; // src/lib.rs:657-658
+    std::vector<int> devices;
     nerf_render_opts opts;
     memset(&opts, 0, sizeof opts);
     opts.n_coarse = 64; opts.n_fine = 128; // default_sample_counts, src/lib.rs:603-612
@@ -40,6 +42,15 @@ int main(int argc, char **argv) {
         else if (a == "--ssaa") opts.ssaa = atoi(next());
         else if (a == "--coarse-only") opts.coarse_only = 1;
         else if (a == "--dtype") { const std::string d = next(); if (d == "bf16") opts.mlp_dtype = NERF_MLP_BF16; else if (d == "bf16x3") opts.mlp_dtype = NERF_MLP_BF16X3; else if (d != "f32") { usage(argv[0]); return 2; } }
+        else if (a == "--skip-empty") opts.skip_empty = 1;
+        else if (a == "--skip-dead") opts.skip_dead = 1;
+        else if (a == "--gpus") gpus = atoi(next());
+        else if (a == "--devices") { // explicit device list, one context each (ids may repeat: several contexts on one GPU)
+            devices.clear();
+            for (const char *p = next(); *p;) { devices.push_back((int)strtol(p, (char **)&p, 10)); if (*p == ',') ++p; else if (*p) { usage(argv[0]); return 2; } }
+            gpus = (int)devices.size();
+        }
+        else if (a == "--gather") { const std::string g = next(); gather = g == "peer" ? NERF_GATHER_PEER : g == "rccl" ? NERF_GATHER_RCCL : NERF_GATHER_HOST; }
         else if (a == "--device") device = atoi(next());
         else if (a == "--frames") frames = atoi(next());
         else if (a == "--out") out = next();
@@ -48,13 +59,17 @@ int main(int argc, char **argv) {
         } else { usage(argv[0]); return a == "--help" || a == "-h" ? 0 : 2; }
     }
 
-    nerf_ctx *ctx = nullptr;
-    if (nerf_create(device, &ctx)) { fprintf(stderr, "error: %s\n", nerf_last_error(nullptr)); return 1; }
-    if (nerf_load_network_dir(ctx, NERF_NET_COARSE, (scene + "/coarse").c_str()) ||
-        nerf_load_network_dir(ctx, NERF_NET_FINE, (scene + "/fine").c_str())) {
-        fprintf(stderr, "error: %s\n", nerf_last_error(ctx));
-        return 1;
-    }
+    // one context per GPU (--gpus N: devices 0..N-1, the rayon fan-out of src/lib.rs:533-550 becomes a fan-out over devices)
+    if (gpus < 1) { usage(argv[0]); return 2; }
+    std::vector<nerf_ctx *> ctxs(gpus, nullptr);
+    if (gpus == 1 && devices.empty() ? nerf_create(device, &ctxs[0]) : nerf_create_multi(devices.empty() ? nullptr : devices.data(), gpus, ctxs.data())) { fprintf(stderr, "error: %s\n", nerf_last_error(nullptr)); return 1; }
+    nerf_ctx *ctx = ctxs[0];
+    for (nerf_ctx *c : ctxs)
+        if (nerf_load_network_dir(c, NERF_NET_COARSE, (scene + "/coarse").c_str()) ||
+            nerf_load_network_dir(c, NERF_NET_FINE, (scene + "/fine").c_str())) {
+            fprintf(stderr, "error: %s\n", nerf_last_error(c));
+            return 1;
+        }
     nerf_camera cam;
     if (nerf_camera_from_json((scene + "/tf_reference_samples.json").c_str(), width, height, &cam)) {
         fprintf(stderr, "error: %s\n", nerf_last_error(nullptr));
@@ -65,10 +80,22 @@ int main(int argc, char **argv) {
     std::vector<float> image((size_t)ow * oh * 3);
     printf("Starting image rendering...\n"); // :667
     nerf_stats st;
+    std::vector<nerf_stats> per(gpus);
     double best = 1e30;
     for (int f = 0; f < frames; ++f) {
         const auto t0 = std::chrono::steady_clock::now(); // Instant::now() :668
-        if (nerf_render_image(ctx, &cam, &opts, image.data(), &st)) { fprintf(stderr, "error: %s\n", nerf_last_error(ctx)); return 1; }
+        if (gpus == 1 ? nerf_render_image(ctx, &cam, &opts, image.data(), &st)
+                      : nerf_render_image_multi(ctxs.data(), gpus, &cam, &opts, gather, image.data(), per.data())) {
+            fprintf(stderr, "error: %s\n", nerf_last_error(ctx));
+            return 1;
+        }
+        if (gpus > 1) { // whole-job view: rays add up, device time is the slowest band's
+            st = per[0];
+            for (int g = 1; g < gpus; ++g) {
+                st.n_rays += per[g].n_rays;
+                if (per[g].ms_total > st.ms_total) { st.ms_total = per[g].ms_total; st.ms_coarse_mlp = per[g].ms_coarse_mlp; st.ms_fine_mlp = per[g].ms_fine_mlp; st.ms_other = per[g].ms_other; }
+            }
+        }
         const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         best = secs < best ? secs : best;
         printf("Rendering complete: %llu/%llu pixels (100.0%%)\n", (unsigned long long)ow * oh, (unsigned long long)ow * oh); // :559-562
@@ -80,12 +107,13 @@ int main(int argc, char **argv) {
                                              : opts.n_coarse * 982528.0 + (double)(opts.n_coarse + opts.n_fine) * 1186816.0;
     const bool bf16 = opts.mlp_dtype != NERF_MLP_F32;
     const double mfma_flops = opts.mlp_dtype == NERF_MLP_BF16X3 ? 6.0 : 1.0; // executed bf16 MFMA flops per algorithmic f32 flop
+    if (gpus > 1) printf("%d GPUs, row bands gathered by %s\n", gpus, gather == NERF_GATHER_PEER ? "xGMI peer copies" : gather == NERF_GATHER_RCCL ? "one RCCL all-gather" : "direct D2H");
     printf("device %s (%d CUs): %.0f rays/s (best of %d, host wall incl. D2H); device %.1f ms = coarse MLP %.1f + fine MLP %.1f + other %.1f; "
            "%.1f%% of the %s MFMA roofline\n",
            arch, n_cus, (double)st.n_rays / best, frames, st.ms_total, st.ms_coarse_mlp, st.ms_fine_mlp, st.ms_other,
-           100.0 * mfma_flops * (double)st.n_rays * flop_ray / (st.ms_total * 1e-3) / (bf16 ? 2500e12 : 157.3e12),
+           100.0 * mfma_flops * (double)st.n_rays * flop_ray / (st.ms_total * 1e-3) / (gpus * (bf16 ? 2500e12 : 157.3e12)),
            bf16 ? "2.5 PFLOP/s bf16" : "157.3 TFLOP/s fp32");
     if (nerf_save_ppm(out.c_str(), ow, oh, image.data())) { fprintf(stderr, "error: %s\n", nerf_last_error(nullptr)); return 1; } // :676
-    nerf_destroy(ctx);
+    for (nerf_ctx *c : ctxs) nerf_destroy(c);
     return 0;
 }

@@ -323,6 +323,12 @@ def test_cli_matches_library(renderer, native, samples, tmp_path):
     assert np.array_equal(np.frombuffer(raw[15:], np.uint8), native.quantize_rgb8(img).reshape(-1))
     bad = subprocess.run([exe, "--scene", str(tmp_path / "nope")], capture_output=True, text=True, timeout=60)
     assert bad.returncode == 1 and "read shapes" in bad.stderr
+    # the same run over three contexts (all on this box's one GPU) with exact dead-sample skipping: the same file, byte for byte
+    out3 = tmp_path / "output3.ppm"
+    res = subprocess.run([exe, "--scene", SCENE, "--out", str(out3), "--devices", "0,0,0", "--gather", "peer", "--skip-dead"],
+                         capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0 and "3 GPUs, row bands gathered by xGMI peer copies" in res.stdout, res.stderr
+    assert out3.read_bytes() == raw
 
 
 def test_packed_blob_loads_identically(renderer, native, tmp_path):
