@@ -313,6 +313,27 @@ def main():
                             "products of three-way splits, f32 accumulate; the coarse (sampling) pass stays on the f32 MFMA kernel, so the "
                             "fine sample positions equal the f32 path's bit for bit; passes the UNRELAXED Gate 1 against the oracle "
                             "(tests/test_gpu_parity.py::test_bf16x3_render_matches_oracle_crop, tests/test_gpu_fullframe.py)"}
+        # ... and with exact dead-sample skipping on top of it (f32 ray-sequential coarse pass, bf16x3 trunk + colour kernels)
+        def x3d_step(stats=False):
+            return N.render_image(r.coarse, r.fine, cam, args.fine, seed=args.seed, ssaa=args.ssaa, dtype="bf16x3", skip_dead=True,
+                                  device_out=frame.data_ptr(), stream=stream, return_stats=stats)
+        x3_step(); torch.cuda.synchronize(dev)
+        x3_frame = frame.clone()
+        st = x3d_step(stats=True); torch.cuda.synchronize(dev)
+        identical = bool(torch.equal(frame, x3_frame))
+        x3d_step(); torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        for _ in range(3):
+            x3d_step()
+        torch.cuda.synchronize(dev)
+        ms = 1e3 * (time.perf_counter() - t1) / 3
+        extra_x3["with_skip_dead"] = {
+            "rays_per_s": args.width * args.height * args.ssaa * args.ssaa / (ms * 1e-3), "ms_per_step": ms,
+            "image_bit_identical_to_the_bf16x3_frame": identical,
+            "executed_fraction_coarse_trunk": st.n_exec_coarse_trunk / max(st.n_coarse_points, 1),
+            "executed_fraction_fine_trunk": st.n_exec_fine_trunk / max(st.n_fine_points, 1),
+            "executed_fraction_colour_head": st.n_exec_colour / max(st.n_fine_points, 1),
+            "device_ms": {"total": st.ms_total, "coarse_trunk_f32": st.ms_coarse_mlp, "fine_trunk_plus_colour_bf16x3": st.ms_fine_mlp, "other": st.ms_other}}
         r.kernel_time_query(reset=True)
     # The timed region leaves the frame in HBM (`value` never includes PCIe); the host-pointer entry point additionally pays
     # one D2H copy of the frame (BASELINE.md section 4 counts it on the GPU side): measured here, reported beside `value`.

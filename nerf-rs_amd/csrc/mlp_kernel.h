@@ -70,3 +70,8 @@ hipError_t nerf_seq_init();
 size_t nerf_seq_h8_bytes(size_t n_samples);
 hipError_t nerf_trunk_seq_launch(const SeqArgs &a, bool export_live, int n_blocks, hipStream_t stream);
 hipError_t nerf_colour_launch(const ColourArgs &a, int n_blocks, hipStream_t stream);
+// the same two kernels in the bf16x3 arithmetic (mlp_kernel_bf16x3.hip): a.wstream is the three-part stream; the h8 tiles and
+// the small parameters have the f32 kernels' layout
+hipError_t nerf_seq_x3_init();
+hipError_t nerf_trunk_seq_x3_launch(const SeqArgs &a, bool export_live, int n_blocks, hipStream_t stream);
+hipError_t nerf_colour_x3_launch(const ColourArgs &a, int n_blocks, hipStream_t stream);

@@ -342,6 +342,222 @@ __global__ __launch_bounds__(256, 1) void nerf_mlp_kernel_bf16x3(const MlpArgs A
     }
 }
 
+// ---- exact dead-sample skipping in this arithmetic (skip_dead with mlp_dtype = NERF_MLP_BF16X3; see mlp_kernel_seq.hip for the
+// scheme): the ray-sequential trunk and the compacted colour head, with this file's layers.  The accumulator tiles have the f32
+// kernel's register layout, so the exported h8 tiles and the small parameters are shared with it.
+namespace {
+constexpr int kH8TileFloatsX3 = 32 * 64 * 4;
+
+__device__ __forceinline__ void pipe_begin(PipeX &P, const LDS_AS char *lds, int lane, int wave, const char *stream, int n_chunks) {
+    P.lane16 = lane * 16;
+    P.ring_lane = lds + P.lane16;
+    P.ring_addr = (uint32_t)(uintptr_t)lds + wave * 6144;
+    P.stream_bytes = n_chunks * kCB;
+    P.gbase = stream + wave * 6144;
+    __syncthreads();
+    pipe_start(P);
+}
+
+__device__ __forceinline__ float lane_value(float v, int k) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), k));
+}
+} // namespace
+
+template <bool EXPORT>
+__global__ __launch_bounds__(256, 1) void nerf_trunk_seq_kernel_x3(const SeqArgs A) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const LDS_AS char *lds = (const LDS_AS char *)smem;
+    const LDS_AS float *small = (const LDS_AS float *)(lds + kRS * kCB);
+    LDS_AS int *vote = (LDS_AS int *)(lds + kRS * kCB) + kMiscOff + 8;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int p = lane & 31;
+    const int h = lane >> 5;
+    {
+        float *dst = (float *)(smem + kRS * kCB);
+        for (int i = tid; i < kSmallFloats; i += 256) dst[i] = A.small_params[i];
+    }
+    PipeX P;
+    pipe_begin(P, lds, lane, wave, (const char *)A.wstream, kChunksSigmaX3);
+
+    const int M = A.samples_per_ray;
+    const int n_chunks = (M + 31) >> 5;
+    int ray = A.n_rays, chunk = n_chunks;
+    float T = 1.0f;
+    unsigned long long chunks_done = 0;
+    for (;;) {
+        if (chunk >= n_chunks) {
+            unsigned r = 0;
+            if (lane == 0) r = atomicAdd(A.ray_counter, 1u);
+            r = (unsigned)__builtin_amdgcn_readfirstlane((int)r);
+            ray = r < (unsigned)A.n_rays ? (int)r : A.n_rays;
+            chunk = 0;
+            T = 1.0f;
+        }
+        const bool has = ray < A.n_rays;
+        if (lane == 0) vote[wave] = has ? 1 : 0;
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if ((vote[0] | vote[1] | vote[2] | vote[3]) == 0) break;
+
+        const int s = chunk * 32 + p;
+        const bool valid = has && s < M;
+        const size_t base = (size_t)(has ? ray : 0) * M;
+        const float t = A.t[base + (s < M ? s : M - 1)];
+        const float t_next = A.t[base + (s + 1 < M ? s + 1 : M - 1)];
+        const float *dv = A.ray_dirs + 3 * (size_t)(has ? ray : 0);
+        const float dx = dv[0], dy = dv[1], dz = dv[2];
+        const float px = __fadd_rn(A.origin[0], __fmul_rn(dx, t));
+        const float py = __fadd_rn(A.origin[1], __fmul_rn(dy, t));
+        const float pz = __fadd_rn(A.origin[2], __fmul_rn(dz, t));
+
+        f32x16 E[2];
+        encode_point<true>(px, py, pz, h, E);
+        f32x16 X[8], Y[8];
+        B3 b;
+        load_bias<8>(X, small + kBiasOff + 0 * 256, h);
+        prep_all<false, 0>(E[0], b);
+        tile_steps<8, false, false, true, false, false>(E[0], E[1], X, b, P);
+        tile_steps<8, false, false, false, false, false>(E[1], E[1], X, b, P);
+        hidden_layer<true>(X, Y, small + kBiasOff + 1 * 256, P, h);
+        hidden_layer<true>(Y, X, small + kBiasOff + 2 * 256, P, h);
+        hidden_layer<true>(X, Y, small + kBiasOff + 3 * 256, P, h);
+        hidden_layer<true>(Y, X, small + kBiasOff + 4 * 256, P, h);
+        load_bias<8>(Y, small + kBiasOff + 5 * 256, h);
+        prep_all<false, 0>(E[0], b);
+        tile_steps<8, false, false, true, false, false>(E[0], E[1], Y, b, P);
+        tile_steps<8, false, false, true, true, true>(E[1], X[0], Y, b, P);
+        eight_tiles<8, true>(X, Y, b, P);
+        tile_steps<8, true, true, false, false, false>(X[7], X[7], Y, b, P);
+        hidden_layer<true>(Y, X, small + kBiasOff + 6 * 256, P, h);
+        hidden_layer<true>(X, Y, small + kBiasOff + 7 * 256, P, h);
+        const float sigma = alpha_head(Y, small, h);
+        if (valid && h == 0) A.sigma_out[base + s] = sigma;
+
+        // compute_weights through this chunk (src/lib.rs:261-280): k_composite's operations in k_composite's order
+        float delta = (s + 1 < M) ? t_next - t : A.far_ - t;
+        if (delta < 0.0f) delta = 0.0f;
+        const float alpha = valid ? 1.0f - expf(-sigma * delta) : 0.0f;
+        float my_w = 0.0f;
+        bool cut = false;
+#pragma unroll
+        for (int k = 0; k < 32; ++k) {
+            const float al = lane_value(alpha, k);
+            const float wk = cut ? 0.0f : T * al;
+            if (p == k) my_w = wk;
+            T = cut ? T : T * (1.0f - al);
+            cut = cut || T < 1e-4f;
+        }
+        if (has) ++chunks_done;
+        if (EXPORT) {
+            const bool live = my_w > 0.0f;
+            const unsigned long long m = __ballot(live) & 0xffffffffull;
+            const int n_live = __popcll(m);
+            if (n_live) {
+                unsigned bs = 0;
+                if (lane == 0) bs = atomicAdd(A.live_count, (unsigned)n_live);
+                bs = (unsigned)__builtin_amdgcn_readfirstlane((int)bs);
+                if (live) {
+                    const unsigned slot = bs + (unsigned)__popcll(m & ((1ull << p) - 1ull));
+                    float *dst = A.h8 + (size_t)(slot >> 5) * kH8TileFloatsX3 + ((slot & 31) + 32 * h) * 4;
+#pragma unroll
+                    for (int tt = 0; tt < 8; ++tt)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            f32x4 v;
+                            v[0] = Y[tt][4 * q + 0]; v[1] = Y[tt][4 * q + 1]; v[2] = Y[tt][4 * q + 2]; v[3] = Y[tt][4 * q + 3];
+                            *(f32x4 *)(dst + (tt * 4 + q) * 256) = v;
+                        }
+                    if (h == 0) A.slot_point[slot] = (unsigned)(base + s);
+                }
+            }
+        }
+        chunk = (cut || !has) ? n_chunks : chunk + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (A.stats && lane == 0 && chunks_done) atomicAdd(A.stats, chunks_done);
+}
+
+__global__ __launch_bounds__(256, 1) void nerf_colour_kernel_x3(const ColourArgs A) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const LDS_AS char *lds = (const LDS_AS char *)smem;
+    const LDS_AS float *small = (const LDS_AS float *)(lds + kRS * kCB);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int p = lane & 31;
+    const int h = lane >> 5;
+    {
+        float *dst = (float *)(smem + kRS * kCB);
+        for (int i = tid; i < kSmallFloats; i += 256) dst[i] = A.small_params[i];
+    }
+    PipeX P;
+    pipe_begin(P, lds, lane, wave, (const char *)A.wstream + (size_t)kChunksSigmaX3 * kCB, kChunksFullX3 - kChunksSigmaX3);
+
+    const unsigned n_live = *A.live_count;
+    const int n_tiles = (int)((n_live + (unsigned)kPointsPerBlock - 1u) / (unsigned)kPointsPerBlock);
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const unsigned slot = (unsigned)tile * kPointsPerBlock + wave * kPointsPerWave + p;
+        const bool valid = slot < n_live;
+        const unsigned i = A.slot_point[valid ? slot : n_live - 1];
+        const float *dv = A.ray_dirs + 3 * (size_t)(i / (unsigned)A.samples_per_ray);
+        const float dx = dv[0], dy = dv[1], dz = dv[2];
+        const float *src = A.h8 + (size_t)(tile * kWavesPerBlock + wave) * kH8TileFloatsX3 + lane * 4;
+        f32x16 X[8], Y[8];
+#pragma unroll
+        for (int tt = 0; tt < 8; ++tt)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 v = *(const f32x4 *)(src + (tt * 4 + q) * 256);
+                Y[tt][4 * q + 0] = v[0]; Y[tt][4 * q + 1] = v[1]; Y[tt][4 * q + 2] = v[2]; Y[tt][4 * q + 3] = v[3];
+            }
+        hidden_layer<true>(Y, X, small + kBiasOff + 8 * 256, P, h); // bottleneck
+        f32x16 D;
+        encode_dir<true>(dx, dy, dz, h, D);
+        f32x16 (&V)[8] = Y;
+        load_bias<4>(V, small + kBiasViewOff, h);
+        B3 b;
+        asm volatile("" : "+a"(X[0]));
+        prep_all<false, 0>(X[0], b);
+        eight_tiles<4, false>(X, V, b, P);
+        tile_steps<4, false, true, true, false, false>(X[7], D, V, b, P);
+        tile_steps<4, false, false, false, false, false>(D, D, V, b, P);
+        float c[3];
+        rgb_head(V, small, h, c);
+        if (valid && h == 0) {
+            A.rgb_out[3 * (size_t)i + 0] = c[0];
+            A.rgb_out[3 * (size_t)i + 1] = c[1];
+            A.rgb_out[3 * (size_t)i + 2] = c[2];
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+hipError_t nerf_seq_x3_init() {
+    const void *ks[3] = {(const void *)nerf_trunk_seq_kernel_x3<true>, (const void *)nerf_trunk_seq_kernel_x3<false>, (const void *)nerf_colour_kernel_x3};
+    for (int i = 0; i < 3; ++i) {
+        hipError_t e = hipFuncSetAttribute(ks[i], hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytesX3);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
+hipError_t nerf_trunk_seq_x3_launch(const SeqArgs &a, bool export_live, int n_blocks, hipStream_t stream) {
+    if (a.n_rays <= 0 || a.samples_per_ray <= 0) return hipSuccess;
+    const long long wave_rays = ((long long)a.n_rays + kWavesPerBlock - 1) / kWavesPerBlock;
+    if (n_blocks > wave_rays) n_blocks = (int)wave_rays;
+    if (n_blocks < 1) n_blocks = 1;
+    if (export_live) hipLaunchKernelGGL(nerf_trunk_seq_kernel_x3<true>, dim3(n_blocks), dim3(256), kLdsBytesX3, stream, a);
+    else hipLaunchKernelGGL(nerf_trunk_seq_kernel_x3<false>, dim3(n_blocks), dim3(256), kLdsBytesX3, stream, a);
+    return hipGetLastError();
+}
+
+hipError_t nerf_colour_x3_launch(const ColourArgs &a, int n_blocks, hipStream_t stream) {
+    if (n_blocks < 1) n_blocks = 1;
+    hipLaunchKernelGGL(nerf_colour_kernel_x3, dim3(n_blocks), dim3(256), kLdsBytesX3, stream, a);
+    return hipGetLastError();
+}
+
 template <bool FULL, int MODE>
 static hipError_t launch_t(const MlpArgs &a, int n_blocks, hipStream_t stream) {
     hipLaunchKernelGGL((nerf_mlp_kernel_bf16x3<FULL, MODE>), dim3(n_blocks), dim3(256), kLdsBytesX3, stream, a);

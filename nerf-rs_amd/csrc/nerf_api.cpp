@@ -248,7 +248,7 @@ int nerfint::render_device(nerf_ctx *c, const nerf_camera *cam, const nerf_rende
     const int dtype_coarse = (dtype == NERF_MLP_BF16X3 && !o->coarse_only) ? NERF_MLP_F32 : dtype;
     if (o->skip_empty != 0 && o->skip_empty != 1) return fail(c, NERF_ERR_INVALID, "skip_empty must be 0 or 1");
     if (o->skip_dead != 0 && o->skip_dead != 1) return fail(c, NERF_ERR_INVALID, "skip_dead must be 0 or 1");
-    if (o->skip_dead && dtype != NERF_MLP_F32) return fail(c, NERF_ERR_INVALID, "skip_dead is implemented for NERF_MLP_F32 only");
+    if (o->skip_dead && dtype == NERF_MLP_BF16) return fail(c, NERF_ERR_INVALID, "skip_dead is implemented for NERF_MLP_F32 and NERF_MLP_BF16X3 only");
     const bool seq = o->skip_dead != 0;
     if (!c->net[NERF_NET_COARSE].loaded) return fail(c, NERF_ERR_STATE, "coarse network not loaded");
     if (!o->coarse_only && !c->net[NERF_NET_FINE].loaded) return fail(c, NERF_ERR_STATE, "fine network not loaded");
@@ -314,27 +314,28 @@ int nerfint::render_device(nerf_ctx *c, const nerf_camera *cam, const nerf_rende
             t.done(c->last_render);
         }
         // skip_dead: one network over the rays of this pass as ray-sequential trunk [+ colour head on the live samples]
-        auto seq_pass = [&](const DevNet &net, int spr, const float *t_in, float *sigma_out, float *rgb_out, int slot, int kind_trunk) -> int {
+        auto seq_pass = [&](const DevNet &net, int dt, int spr, const float *t_in, float *sigma_out, float *rgb_out, int slot, int kind_trunk) -> int {
+            const bool x3 = dt == NERF_MLP_BF16X3;
             unsigned int *ctr = c->d_seq + 4 * (size_t)slot;
             HIP_TRY(c, hipMemsetAsync(sigma_out, 0, (size_t)n_rays * spr * sizeof(float), st)); // samples behind the cut stay 0
             if (rgb_out) HIP_TRY(c, hipMemsetAsync(rgb_out, 0, (size_t)n_rays * spr * 3 * sizeof(float), st)); // weight-0 samples: 0 * 0
             SeqArgs q{};
-            q.wstream = net.wstream; q.small_params = net.small; q.n_rays = n_rays; q.samples_per_ray = spr;
+            q.wstream = stream_of(net, dt); q.small_params = net.small; q.n_rays = n_rays; q.samples_per_ray = spr;
             q.ray_dirs = c->d_dirs; q.t = t_in; q.far_ = cam->far_;
             q.origin[0] = cam->pos[0]; q.origin[1] = cam->pos[1]; q.origin[2] = cam->pos[2];
             q.sigma_out = sigma_out; q.ray_counter = ctr; q.live_count = ctr + 1; q.h8 = c->d_h8; q.slot_point = c->d_slot_point;
             q.stats = (unsigned long long *)(ctr + 2);
             {
                 Timed t(c, st, kind_trunk, (uint64_t)n_rays * spr, timing);
-                HIP_TRY(c, nerf_trunk_seq_launch(q, rgb_out != nullptr, c->n_cus, st));
+                HIP_TRY(c, x3 ? nerf_trunk_seq_x3_launch(q, rgb_out != nullptr, c->n_cus, st) : nerf_trunk_seq_launch(q, rgb_out != nullptr, c->n_cus, st));
                 t.done(c->last_render);
             }
             if (rgb_out) {
                 ColourArgs k{};
-                k.wstream = net.wstream; k.small_params = net.small; k.live_count = ctr + 1; k.h8 = c->d_h8; k.slot_point = c->d_slot_point;
+                k.wstream = stream_of(net, dt); k.small_params = net.small; k.live_count = ctr + 1; k.h8 = c->d_h8; k.slot_point = c->d_slot_point;
                 k.ray_dirs = c->d_dirs; k.samples_per_ray = spr; k.rgb_out = rgb_out;
                 Timed t(c, st, 4, 0, timing);
-                HIP_TRY(c, nerf_colour_launch(k, c->n_cus, st));
+                HIP_TRY(c, x3 ? nerf_colour_x3_launch(k, c->n_cus, st) : nerf_colour_launch(k, c->n_cus, st));
                 t.done(c->last_render);
             }
             return NERF_OK;
@@ -349,7 +350,7 @@ int nerfint::render_device(nerf_ctx *c, const nerf_camera *cam, const nerf_rende
         a.sigma_out = c->d_sc; a.rgb_out = c->d_rgbc;
         a.skip_empty = o->skip_empty; a.skip_counter = o->skip_empty ? c->d_skip : nullptr; // only full kernels look at it
         if (seq) {
-            if ((rc = seq_pass(NC, nc, c->d_tc, c->d_sc, o->coarse_only ? c->d_rgbc : nullptr, 2 * (int)passes, o->coarse_only ? 1 : 0))) return rc;
+            if ((rc = seq_pass(NC, dtype_coarse, nc, c->d_tc, c->d_sc, o->coarse_only ? c->d_rgbc : nullptr, 2 * (int)passes, o->coarse_only ? 1 : 0))) return rc;
         } else {
             Timed t(c, st, o->coarse_only ? 1 : 0, (uint64_t)a.n_points, timing);
             HIP_TRY(c, launch_mlp(c, dtype_coarse, a, o->coarse_only != 0, st));
@@ -382,7 +383,7 @@ int nerfint::render_device(nerf_ctx *c, const nerf_camera *cam, const nerf_rende
         a.clock_out = c->d_clock; // NULL unless NERF_DEBUG_CLOCK=1
         c->clock_valid = c->d_clock != nullptr;
         if (seq) {
-            if ((rc = seq_pass(NF, M, t_fine, c->d_sf, c->d_rgbf, 2 * (int)passes + 1, 1))) return rc;
+            if ((rc = seq_pass(NF, dtype, M, t_fine, c->d_sf, c->d_rgbf, 2 * (int)passes + 1, 1))) return rc;
         } else {
             Timed t(c, st, 1, (uint64_t)a.n_points, timing);
             HIP_TRY(c, launch_mlp(c, dtype, a, true, st));
@@ -510,6 +511,7 @@ int nerf_create(int device_id, nerf_ctx **out) try {
     if (e1 == hipSuccess) e1 = nerf_mlp_bf16v2_init();
     if (e1 == hipSuccess) e1 = nerf_mlp_bf16x3_init();
     if (e1 == hipSuccess) e1 = nerf_seq_init();
+    if (e1 == hipSuccess) e1 = nerf_seq_x3_init();
     hipError_t e2 = e1 == hipSuccess ? sampling_init() : e1;
     hipError_t e3 = e2 == hipSuccess ? hipStreamCreate(&c->stream) : e2;
     if (e3 != hipSuccess) {

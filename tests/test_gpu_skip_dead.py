@@ -99,4 +99,30 @@ def test_skip_dead_argument_errors(renderer, native, samples):
     cam = native.camera_from_samples(samples, 64, 64, 64)
     with pytest.raises(native.NerfError) as e:
         native.render_image(renderer.coarse, renderer.fine, cam, 128, skip_dead=True, dtype="bf16")
-    assert e.value.code == -1 and "NERF_MLP_F32 only" in e.value.msg
+    assert e.value.code == -1 and "NERF_MLP_F32 and NERF_MLP_BF16X3 only" in e.value.msg
+
+
+def test_skip_dead_in_bf16x3_arithmetic(renderer, native, samples):
+    """skip_dead with mlp_dtype = bf16x3: f32 ray-sequential coarse pass + bf16x3 ray-sequential fine trunk + bf16x3 colour head on
+    the live samples.  Bit-identical to the non-skipping bf16x3 frame (whole C3 frame and ragged variants), Gate 1 against the
+    oracle's crop."""
+    cam = native.camera_from_samples(samples, 800, 800, 64)
+    g = golden("crop_c3_800_64_128.npz")
+    crop = tuple(int(v) for v in g["crop"])
+    ref = native.render_image(renderer.coarse, renderer.fine, cam, 128, seed=0, crop=crop, dtype="bf16x3")
+    img, st = native.render_image(renderer.coarse, renderer.fine, cam, 128, seed=0, crop=crop, dtype="bf16x3", skip_dead=True, return_stats=True)
+    assert np.array_equal(img, ref)
+    _gate1(img, g["image"])
+    assert st.n_exec_fine_trunk < 0.98 * st.n_fine_points and 0 < st.n_exec_colour < 0.7 * st.n_fine_points
+    cam40 = native.camera_from_samples(samples, 800, 800, 40)
+    a = native.render_image(renderer.coarse, renderer.fine, cam40, 50, seed=2, crop=(380, 360, 40, 24), dtype="bf16x3", skip_dead=True)
+    assert np.array_equal(a, native.render_image(renderer.coarse, renderer.fine, cam40, 50, seed=2, crop=(380, 360, 40, 24), dtype="bf16x3"))
+    cam4 = native.camera_from_samples(samples, 400, 400, 64)
+    c = native.render_image(renderer.coarse, renderer.fine, cam4, 0, seed=0, coarse_only=True, crop=(150, 150, 100, 40), dtype="bf16x3", skip_dead=True)
+    assert np.array_equal(c, native.render_image(renderer.coarse, renderer.fine, cam4, 0, seed=0, coarse_only=True, crop=(150, 150, 100, 40), dtype="bf16x3"))
+    full_ref = native.render_image(renderer.coarse, renderer.fine, cam, 128, seed=0, dtype="bf16x3")
+    full, st = native.render_image(renderer.coarse, renderer.fine, cam, 128, seed=0, dtype="bf16x3", skip_dead=True, return_stats=True)
+    assert np.array_equal(full, full_ref)
+    print(f"\nskip_dead bf16x3 full frame: {st.n_rays / (st.ms_total * 1e-3):.0f} rays/s, ms total {st.ms_total:.1f} "
+          f"(coarse {st.ms_coarse_mlp:.1f} fine {st.ms_fine_mlp:.1f} other {st.ms_other:.1f}); fine trunk {st.n_exec_fine_trunk / st.n_fine_points:.4f}, "
+          f"colour {st.n_exec_colour / st.n_fine_points:.4f}")
