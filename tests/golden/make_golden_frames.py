@@ -2,7 +2,7 @@
 """Whole-frame fixtures from the CPU oracle (oracle/nerf_oracle.c) for the GPU suite, which cannot run the oracle at
 this size (the GPU box has no /root/reference and the -m gpu suite must stay short).
 
-    python tests/golden/make_golden_frames.py [threads]     # ~20 min on 16 fast cores, hours on 8 slow ones; rewrites the two files below
+    python tests/golden/make_golden_frames.py [threads] [--parts=seed0,seed1,ssaa2]     # ~20 min on 16 fast cores, hours on 8 slow ones; rewrites the two files below
 
   frame_c3_800_seed0.npz   BASELINE config C3 (lego 800x800, 64 + 128 samples/ray, f32), seed 0: the oracle's whole frame
                            (`image`, 800 x 800 x 3 f32 linear RGB) and its save_ppm quantisation (`rgb8`, src/lib.rs:573-577)
@@ -45,28 +45,44 @@ def heartbeat(t0):
 
 
 def main():
-    threads = int(sys.argv[1]) if len(sys.argv) > 1 else len(os.sched_getaffinity(0))
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    threads = int(args[0]) if args else len(os.sched_getaffinity(0))
+    parts = "seed0,seed1,ssaa2"
+    for a in sys.argv[1:]:
+        if a.startswith("--parts="):
+            parts = a.split("=", 1)[1]   # e.g. --parts=ssaa2: reuse the committed seed-0 frame, add one number to frame_gates.json
+    parts = parts.split(",")
     os.makedirs(OUT, exist_ok=True)
     S = O.load_samples(os.path.join(SCENE, "tf_reference_samples.json"))
     co, fi = O.Net(os.path.join(SCENE, "coarse")), O.Net(os.path.join(SCENE, "fine"))
     cam = O.camera_from_samples(S, 800, 800)
+    committed = os.path.join(ROOT, "tests", "golden")
+    gates_path = os.path.join(OUT, "frame_gates.json")
     gates = {"config": "lego 800x800, 64 + 128 samples/ray, f32 oracle; A = seed-0 frame (frame_c3_800_seed0.npz)"}
+    for cand in (gates_path, os.path.join(committed, "frame_gates.json")):
+        if os.path.exists(cand):
+            gates.update(json.load(open(cand)))
+            break
     t0 = time.time()
     heartbeat(t0)
-    a = O.render_image(co, fi, cam, O.make_opts(64, 128, seed=0, threads=threads))
-    gates["oracle_seconds_seed0"] = round(time.time() - t0, 1); gates["oracle_threads"] = threads
-    np.savez_compressed(os.path.join(OUT, "frame_c3_800_seed0.npz"), image=a, rgb8=O.quantize_rgb8(a), seed=np.uint64(0),
-                        n_coarse=64, n_fine=128, width=800, height=800)
-    print("seed 0 frame written after %.0f s; white fraction %.4f" % (time.time() - t0, float((a == 1.0).all(axis=2).mean())), flush=True)
-    b = O.render_image(co, fi, cam, O.make_opts(64, 128, seed=1, threads=threads))
-    gates["cpu_seed1_vs_A"] = psnr(b, a)
-    json.dump(gates, open(os.path.join(OUT, "frame_gates.json"), "w"), indent=1)
-    print("seed 1:", gates["cpu_seed1_vs_A"], flush=True)
-    c = O.render_image(co, fi, cam, O.make_opts(64, 128, seed=1, ssaa=2, threads=threads))
-    gates["cpu_ssaa2_seed1_vs_A"] = psnr(c, a)
-    gates["oracle_seconds_total"] = round(time.time() - t0, 1)
-    json.dump(gates, open(os.path.join(OUT, "frame_gates.json"), "w"), indent=1)
-    print("ssaa2 seed 1:", gates["cpu_ssaa2_seed1_vs_A"], "total %.0f s" % (time.time() - t0), flush=True)
+    if "seed0" in parts:
+        a = O.render_image(co, fi, cam, O.make_opts(64, 128, seed=0, threads=threads))
+        gates["oracle_seconds_seed0"] = round(time.time() - t0, 1); gates["oracle_threads"] = threads
+        np.savez_compressed(os.path.join(OUT, "frame_c3_800_seed0.npz"), image=a, rgb8=O.quantize_rgb8(a), seed=np.uint64(0),
+                            n_coarse=64, n_fine=128, width=800, height=800)
+        print("seed 0 frame written after %.0f s; white fraction %.4f" % (time.time() - t0, float((a == 1.0).all(axis=2).mean())), flush=True)
+    else:
+        a = np.load(os.path.join(committed, "frame_c3_800_seed0.npz"))["image"]
+    if "seed1" in parts:
+        b = O.render_image(co, fi, cam, O.make_opts(64, 128, seed=1, threads=threads))
+        gates["cpu_seed1_vs_A"] = psnr(b, a)
+        json.dump(gates, open(gates_path, "w"), indent=1)
+        print("seed 1:", gates["cpu_seed1_vs_A"], flush=True)
+    if "ssaa2" in parts:
+        c = O.render_image(co, fi, cam, O.make_opts(64, 128, seed=1, ssaa=2, threads=threads))
+        gates["cpu_ssaa2_seed1_vs_A"] = psnr(c, a)
+        json.dump(gates, open(gates_path, "w"), indent=1)
+        print("ssaa2 seed 1:", gates["cpu_ssaa2_seed1_vs_A"], "total %.0f s" % (time.time() - t0), flush=True)
 
 
 if __name__ == "__main__":
