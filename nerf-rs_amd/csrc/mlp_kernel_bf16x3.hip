@@ -24,6 +24,7 @@
 #include "mlp_common.hip.h"
 #include "mlp_kernel.h"
 #include "mlp_layout.h"
+#include "mlp_seq_common.hip.h"
 
 using namespace nerfmlp;
 using namespace mlpdev;
@@ -342,12 +343,10 @@ __global__ __launch_bounds__(256, 1) void nerf_mlp_kernel_bf16x3(const MlpArgs A
     }
 }
 
-// ---- exact dead-sample skipping in this arithmetic (skip_dead with mlp_dtype = NERF_MLP_BF16X3; see mlp_kernel_seq.hip for the
-// scheme): the ray-sequential trunk and the compacted colour head, with this file's layers.  The accumulator tiles have the f32
-// kernel's register layout, so the exported h8 tiles and the small parameters are shared with it.
+// ---- exact dead-sample skipping in this arithmetic (skip_dead with mlp_dtype = NERF_MLP_BF16X3; scheme: mlp_kernel_seq.hip,
+// shared half: mlp_seq_common.hip.h): the ray-sequential trunk and the compacted colour head with this file's layers.  The
+// accumulator tiles have the f32 kernel's register layout, so the exported h8 tiles and the small parameters are shared with it.
 namespace {
-constexpr int kH8TileFloatsX3 = 32 * 64 * 4;
-
 __device__ __forceinline__ void pipe_begin(PipeX &P, const LDS_AS char *lds, int lane, int wave, const char *stream, int n_chunks) {
     P.lane16 = lane * 16;
     P.ring_lane = lds + P.lane16;
@@ -357,14 +356,11 @@ __device__ __forceinline__ void pipe_begin(PipeX &P, const LDS_AS char *lds, int
     __syncthreads();
     pipe_start(P);
 }
-
-__device__ __forceinline__ float lane_value(float v, int k) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), k));
-}
 } // namespace
 
 template <bool EXPORT>
 __global__ __launch_bounds__(256, 1) void nerf_trunk_seq_kernel_x3(const SeqArgs A) {
+    using namespace mlpseq;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const LDS_AS char *lds = (const LDS_AS char *)smem;
     const LDS_AS float *small = (const LDS_AS float *)(lds + kRS * kCB);
@@ -381,38 +377,12 @@ __global__ __launch_bounds__(256, 1) void nerf_trunk_seq_kernel_x3(const SeqArgs
     PipeX P;
     pipe_begin(P, lds, lane, wave, (const char *)A.wstream, kChunksSigmaX3);
 
-    const int M = A.samples_per_ray;
-    const int n_chunks = (M + 31) >> 5;
-    int ray = A.n_rays, chunk = n_chunks;
-    float T = 1.0f;
-    unsigned long long chunks_done = 0;
-    for (;;) {
-        if (chunk >= n_chunks) {
-            unsigned r = 0;
-            if (lane == 0) r = atomicAdd(A.ray_counter, 1u);
-            r = (unsigned)__builtin_amdgcn_readfirstlane((int)r);
-            ray = r < (unsigned)A.n_rays ? (int)r : A.n_rays;
-            chunk = 0;
-            T = 1.0f;
-        }
-        const bool has = ray < A.n_rays;
-        if (lane == 0) vote[wave] = has ? 1 : 0;
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        if ((vote[0] | vote[1] | vote[2] | vote[3]) == 0) break;
-
-        const int s = chunk * 32 + p;
-        const bool valid = has && s < M;
-        const size_t base = (size_t)(has ? ray : 0) * M;
-        const float t = A.t[base + (s < M ? s : M - 1)];
-        const float t_next = A.t[base + (s + 1 < M ? s + 1 : M - 1)];
-        const float *dv = A.ray_dirs + 3 * (size_t)(has ? ray : 0);
-        const float dx = dv[0], dy = dv[1], dz = dv[2];
-        const float px = __fadd_rn(A.origin[0], __fmul_rn(dx, t));
-        const float py = __fadd_rn(A.origin[1], __fmul_rn(dy, t));
-        const float pz = __fadd_rn(A.origin[2], __fmul_rn(dz, t));
-
+    RayWork W;
+    work_init(W, A);
+    while (work_acquire(W, A, vote, wave, lane)) {
+        const ChunkIn c = chunk_inputs(W, A, p);
         f32x16 E[2];
-        encode_point<true>(px, py, pz, h, E);
+        encode_point<true>(c.px, c.py, c.pz, h, E);
         f32x16 X[8], Y[8];
         B3 b;
         load_bias<8>(X, small + kBiasOff + 0 * 256, h);
@@ -432,60 +402,20 @@ __global__ __launch_bounds__(256, 1) void nerf_trunk_seq_kernel_x3(const SeqArgs
         hidden_layer<true>(Y, X, small + kBiasOff + 6 * 256, P, h);
         hidden_layer<true>(X, Y, small + kBiasOff + 7 * 256, P, h);
         const float sigma = alpha_head(Y, small, h);
-        if (valid && h == 0) A.sigma_out[base + s] = sigma;
-
-        // compute_weights through this chunk (src/lib.rs:261-280): k_composite's operations in k_composite's order
-        float delta = (s + 1 < M) ? t_next - t : A.far_ - t;
-        if (delta < 0.0f) delta = 0.0f;
-        const float alpha = valid ? 1.0f - expf(-sigma * delta) : 0.0f;
-        float my_w = 0.0f;
-        bool cut = false;
-#pragma unroll
-        for (int k = 0; k < 32; ++k) {
-            const float al = lane_value(alpha, k);
-            const float wk = cut ? 0.0f : T * al;
-            if (p == k) my_w = wk;
-            T = cut ? T : T * (1.0f - al);
-            cut = cut || T < 1e-4f;
-        }
-        if (has) ++chunks_done;
-        if (EXPORT) {
-            const bool live = my_w > 0.0f;
-            const unsigned long long m = __ballot(live) & 0xffffffffull;
-            const int n_live = __popcll(m);
-            if (n_live) {
-                unsigned bs = 0;
-                if (lane == 0) bs = atomicAdd(A.live_count, (unsigned)n_live);
-                bs = (unsigned)__builtin_amdgcn_readfirstlane((int)bs);
-                if (live) {
-                    const unsigned slot = bs + (unsigned)__popcll(m & ((1ull << p) - 1ull));
-                    float *dst = A.h8 + (size_t)(slot >> 5) * kH8TileFloatsX3 + ((slot & 31) + 32 * h) * 4;
-#pragma unroll
-                    for (int tt = 0; tt < 8; ++tt)
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            f32x4 v;
-                            v[0] = Y[tt][4 * q + 0]; v[1] = Y[tt][4 * q + 1]; v[2] = Y[tt][4 * q + 2]; v[3] = Y[tt][4 * q + 3];
-                            *(f32x4 *)(dst + (tt * 4 + q) * 256) = v;
-                        }
-                    if (h == 0) A.slot_point[slot] = (unsigned)(base + s);
-                }
-            }
-        }
-        chunk = (cut || !has) ? n_chunks : chunk + 1;
+        chunk_finish<EXPORT>(W, A, c, sigma, Y, lane, p, h);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (A.stats && lane == 0 && chunks_done) atomicAdd(A.stats, chunks_done);
+    work_done(W, A, lane);
 }
 
 __global__ __launch_bounds__(256, 1) void nerf_colour_kernel_x3(const ColourArgs A) {
+    using namespace mlpseq;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const LDS_AS char *lds = (const LDS_AS char *)smem;
     const LDS_AS float *small = (const LDS_AS float *)(lds + kRS * kCB);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int p = lane & 31;
     const int h = lane >> 5;
     {
         float *dst = (float *)(smem + kRS * kCB);
@@ -494,26 +424,14 @@ __global__ __launch_bounds__(256, 1) void nerf_colour_kernel_x3(const ColourArgs
     PipeX P;
     pipe_begin(P, lds, lane, wave, (const char *)A.wstream + (size_t)kChunksSigmaX3 * kCB, kChunksFullX3 - kChunksSigmaX3);
 
-    const unsigned n_live = *A.live_count;
-    const int n_tiles = (int)((n_live + (unsigned)kPointsPerBlock - 1u) / (unsigned)kPointsPerBlock);
+    unsigned n_live;
+    const int n_tiles = colour_tiles(A, &n_live);
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        const unsigned slot = (unsigned)tile * kPointsPerBlock + wave * kPointsPerWave + p;
-        const bool valid = slot < n_live;
-        const unsigned i = A.slot_point[valid ? slot : n_live - 1];
-        const float *dv = A.ray_dirs + 3 * (size_t)(i / (unsigned)A.samples_per_ray);
-        const float dx = dv[0], dy = dv[1], dz = dv[2];
-        const float *src = A.h8 + (size_t)(tile * kWavesPerBlock + wave) * kH8TileFloatsX3 + lane * 4;
         f32x16 X[8], Y[8];
-#pragma unroll
-        for (int tt = 0; tt < 8; ++tt)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const f32x4 v = *(const f32x4 *)(src + (tt * 4 + q) * 256);
-                Y[tt][4 * q + 0] = v[0]; Y[tt][4 * q + 1] = v[1]; Y[tt][4 * q + 2] = v[2]; Y[tt][4 * q + 3] = v[3];
-            }
+        const ColourIn c = colour_inputs(A, n_live, tile, wave, lane, Y);
         hidden_layer<true>(Y, X, small + kBiasOff + 8 * 256, P, h); // bottleneck
         f32x16 D;
-        encode_dir<true>(dx, dy, dz, h, D);
+        encode_dir<true>(c.dx, c.dy, c.dz, h, D);
         f32x16 (&V)[8] = Y;
         load_bias<4>(V, small + kBiasViewOff, h);
         B3 b;
@@ -522,13 +440,9 @@ __global__ __launch_bounds__(256, 1) void nerf_colour_kernel_x3(const ColourArgs
         eight_tiles<4, false>(X, V, b, P);
         tile_steps<4, false, true, true, false, false>(X[7], D, V, b, P);
         tile_steps<4, false, false, false, false, false>(D, D, V, b, P);
-        float c[3];
-        rgb_head(V, small, h, c);
-        if (valid && h == 0) {
-            A.rgb_out[3 * (size_t)i + 0] = c[0];
-            A.rgb_out[3 * (size_t)i + 1] = c[1];
-            A.rgb_out[3 * (size_t)i + 2] = c[2];
-        }
+        float rgb[3];
+        rgb_head(V, small, h, rgb);
+        colour_store(A, c, rgb, h);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
@@ -544,9 +458,7 @@ hipError_t nerf_seq_x3_init() {
 
 hipError_t nerf_trunk_seq_x3_launch(const SeqArgs &a, bool export_live, int n_blocks, hipStream_t stream) {
     if (a.n_rays <= 0 || a.samples_per_ray <= 0) return hipSuccess;
-    const long long wave_rays = ((long long)a.n_rays + kWavesPerBlock - 1) / kWavesPerBlock;
-    if (n_blocks > wave_rays) n_blocks = (int)wave_rays;
-    if (n_blocks < 1) n_blocks = 1;
+    n_blocks = mlpseq::trunk_blocks(a, n_blocks);
     if (export_live) hipLaunchKernelGGL(nerf_trunk_seq_kernel_x3<true>, dim3(n_blocks), dim3(256), kLdsBytesX3, stream, a);
     else hipLaunchKernelGGL(nerf_trunk_seq_kernel_x3<false>, dim3(n_blocks), dim3(256), kLdsBytesX3, stream, a);
     return hipGetLastError();

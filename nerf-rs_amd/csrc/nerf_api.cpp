@@ -12,6 +12,8 @@
 #include <string.h>
 
 #include <algorithm>
+#include <mutex>
+#include <set>
 #include <string>
 #include <vector>
 
@@ -507,12 +509,22 @@ int nerf_create(int device_id, nerf_ctx **out) try {
         if (atoi(env) > 0 && hipMalloc((void **)&c->d_clock, (size_t)c->n_cus * 2 * sizeof(unsigned long long)) != hipSuccess) c->d_clock = nullptr;
     }
     if (hipMalloc((void **)&c->d_skip, sizeof(unsigned long long)) != hipSuccess) c->d_skip = nullptr;
-    hipError_t e1 = nerf_mlp_init();
-    if (e1 == hipSuccess) e1 = nerf_mlp_bf16v2_init();
-    if (e1 == hipSuccess) e1 = nerf_mlp_bf16x3_init();
-    if (e1 == hipSuccess) e1 = nerf_seq_init();
-    if (e1 == hipSuccess) e1 = nerf_seq_x3_init();
-    hipError_t e2 = e1 == hipSuccess ? sampling_init() : e1;
+    // kernel attributes (dynamic LDS sizes) are per device, not per context: set them once per device and process
+    static std::mutex init_mu;
+    static std::set<int> init_done;
+    hipError_t e1 = hipSuccess, e2 = hipSuccess;
+    {
+        std::lock_guard<std::mutex> lk(init_mu);
+        if (!init_done.count(device_id)) {
+            e1 = nerf_mlp_init();
+            if (e1 == hipSuccess) e1 = nerf_mlp_bf16v2_init();
+            if (e1 == hipSuccess) e1 = nerf_mlp_bf16x3_init();
+            if (e1 == hipSuccess) e1 = nerf_seq_init();
+            if (e1 == hipSuccess) e1 = nerf_seq_x3_init();
+            e2 = e1 == hipSuccess ? sampling_init() : e1;
+            if (e2 == hipSuccess) init_done.insert(device_id);
+        }
+    }
     hipError_t e3 = e2 == hipSuccess ? hipStreamCreate(&c->stream) : e2;
     if (e3 != hipSuccess) {
         const std::string m = std::string("context initialisation failed: ") + hipGetErrorString(e3);
