@@ -270,7 +270,12 @@ int nerfint::render_device(nerf_ctx *c, const nerf_camera *cam, const nerf_rende
     // a pass must keep rays * samples within int32 (kernel indices) as well as within the configured budget
     size_t pass_cap = std::min<size_t>(c->max_rays_per_pass, (size_t)0x3fffffff / (size_t)M);
     // skip_dead: the compacted trunk outputs are sized for the worst case (every sample of a pass live, 1 KiB each)
-    if (seq) pass_cap = std::min<size_t>(pass_cap, std::max<size_t>(1, c->max_export_bytes / ((size_t)M * 1024)));
+    if (seq) {
+        size_t budget = c->max_export_bytes, free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) // never more than half of what the device can still give (plus what we already hold)
+            budget = std::min(budget, (free_b + c->h8_bytes) / 2);
+        pass_cap = std::min<size_t>(pass_cap, std::max<size_t>(1, budget / ((size_t)M * 1024)));
+    }
     if ((size_t)RW > pass_cap && (size_t)RW * M > (size_t)0x3fffffff) return fail(c, NERF_ERR_INVALID, "ray row too wide for one pass");
     const size_t rows_per_pass = std::max<size_t>(1, std::min<size_t>(RH, pass_cap / (size_t)RW));
     if ((rc = ensure_workspace(c, rows_per_pass * RW, nc, M))) return rc;
