@@ -312,7 +312,7 @@ def main():
                     "note": "opt-in mlp_dtype bf16x3: the fine (colour) pass computes every f32 product as the six significant bf16 x bf16 "
                             "products of three-way splits, f32 accumulate; the coarse (sampling) pass stays on the f32 MFMA kernel, so the "
                             "fine sample positions equal the f32 path's bit for bit; passes the UNRELAXED Gate 1 against the oracle "
-                            "(tests/test_gpu_parity.py::test_bf16x3_render_matches_oracle_crop, tests/test_gpu_fullframe.py)"}
+                            "(tests/test_gpu_parity.py::test_bf16x3_render_matches_oracle_crop, tests/test_gpu_frame_fixture.py)"}
         # ... and with exact dead-sample skipping on top of it (f32 ray-sequential coarse pass, bf16x3 trunk + colour kernels)
         def x3d_step(stats=False):
             return N.render_image(r.coarse, r.fine, cam, args.fine, seed=args.seed, ssaa=args.ssaa, dtype="bf16x3", skip_dead=True,

@@ -1,11 +1,12 @@
 """Full-frame parity of the headline configuration (BASELINE config C3: lego 800x800, 64 + 128 samples, f32): the whole GPU
 frame against the whole CPU-oracle frame, same seed.  The oracle needs ~3 minutes of 16 host threads for the 640 000 rays,
-so the test only runs when NERF_FULLFRAME=1 (the regular suite checks the same configuration on committed crops):
+so it is NOT part of the regular suite (the file name keeps pytest from collecting it): the regular -m gpu suite holds the same
+whole frame to the unrelaxed Gate 1 against the COMMITTED oracle frame (tests/test_gpu_frame_fixture.py).  Run it by name:
 
-    NERF_FULLFRAME=1 python -m pytest tests/test_gpu_fullframe.py -q -m gpu -s
+    NERF_FULLFRAME=1 python -m pytest tests/gpu_fullframe_live_oracle.py -q -m gpu -s
 
-It prints one JSON line (kept as profiles/parity_fullframe_r01.json) and enforces: PSNR(GPU, CPU) >= 80 dB; |d| > 5e-5 on at
-most 0.1 % of the channel values and never above 2e-3 (the path is discontinuous in a few places -- a 1e-5 relative
+It prints one JSON line (round 1: profiles/parity_fullframe_r01.json) and enforces: PSNR(GPU, CPU) >= 90 dB; |d| > 5e-5 on at
+most 0.1 % of the channel values and never above 5e-4 (the path is discontinuous in a few places -- a 1e-5 relative
 difference in a coarse density can move a CDF entry across a fixed uniform draw, which relocates one fine sample: the
 measured frame has a handful of such pixels, max 2.4e-4, against a mean of 4.9e-8); 8-bit output identical in >= 99.99 % of
 the channel values and never more than one step apart; Gate 2 of the north star on the full frame
@@ -61,12 +62,12 @@ def test_full_frame_c3_matches_oracle(renderer, native, oracle, oracle_nets, sam
     }
     print("\nFULLFRAME " + json.dumps(rec))
     assert np.isfinite(gpu0).all() and np.isfinite(b16_0).all()
-    assert rec["f32_max_abs_diff"] <= 2e-3 and rec["f32_fraction_above_5e-5"] <= 1e-3 and rec["f32_psnr_gpu_vs_cpu_db"] >= 80.0
+    assert rec["f32_max_abs_diff"] <= 5e-4 and rec["f32_fraction_above_5e-5"] <= 1e-3 and rec["f32_psnr_gpu_vs_cpu_db"] >= 90.0
     assert rec["rgb8_equal_fraction"] >= 0.9999 and rec["rgb8_max_step"] <= 1
     assert abs(rec["gate2_gpu_f32_seed1_vs_cpu_seed0_db"] - rec["gate2_cpu_seed1_vs_cpu_seed0_db"]) <= 0.1
     assert abs(rec["gate2_gpu_bf16_seed1_vs_cpu_seed0_db"] - rec["gate2_cpu_seed1_vs_cpu_seed0_db"]) <= 0.1
     assert rec["bf16_vs_f32_gpu_same_seed_db"] >= 45.0
-    # the opt-in bf16x3 arithmetic is held to the f32 path's bounds
-    assert rec["bf16x3_max_abs_diff"] <= 2e-2 and rec["bf16x3_fraction_above_5e-5"] <= 1e-3 and rec["bf16x3_psnr_gpu_vs_cpu_db"] >= 80.0
-    assert rec["bf16x3_rgb8_equal_fraction"] >= 0.9999 and rec["bf16x3_rgb8_max_step"] <= 2
+    # the opt-in bf16x3 arithmetic is held to the f32 path's bounds (unrelaxed since the coarse pass runs on the f32 kernel)
+    assert rec["bf16x3_max_abs_diff"] <= 5e-4 and rec["bf16x3_fraction_above_5e-5"] <= 1e-3 and rec["bf16x3_psnr_gpu_vs_cpu_db"] >= 90.0
+    assert rec["bf16x3_rgb8_equal_fraction"] >= 0.9999 and rec["bf16x3_rgb8_max_step"] <= 1
     assert abs(rec["gate2_gpu_bf16x3_seed1_vs_cpu_seed0_db"] - rec["gate2_cpu_seed1_vs_cpu_seed0_db"]) <= 0.1
