@@ -183,16 +183,30 @@ def main():
     dev = torch.device("cuda", dev_index)
     # NERF_BENCH_FORCE_DIST=1 drives the N > 1 code path (process group, band split, RCCL all-gather) at world size 1
     use_dist = world > 1 or os.environ.get("NERF_BENCH_FORCE_DIST") == "1"
+    data_group = None  # the process group of the ONE data-path collective (None = the default group)
+    backend = "none"
     if use_dist:
         if world == 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29511")
         # nccl == RCCL on ROCm.  RCCL refuses two ranks on one device, so a rehearsal of N ranks on fewer GPUs (a 1-GPU
-        # test box) falls back to gloo on host copies of the bands -- and says so in the JSON line.
-        backend = os.environ.get("NERF_BENCH_BACKEND", "nccl" if n_visible >= world else "gloo")
+        # test box) falls back to gloo on host copies of the bands -- and says so in the JSON line.  If fewer devices are
+        # visible than ranks, a launcher may still have given every rank its own GPU (per-rank *_VISIBLE_DEVICES): the ranks
+        # exchange their device identities over gloo first and use RCCL when they are all different.
+        backend = os.environ.get("NERF_BENCH_BACKEND", "nccl" if n_visible >= world else "")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+            if backend == "":
+                props = torch.cuda.get_device_properties(dev_index)
+                ident = tuple(str(getattr(props, k)) for k in ("uuid", "pci_domain_id", "pci_bus_id", "pci_device_id") if hasattr(props, k)) or None
+                ids = [None] * world
+                dist.all_gather_object(ids, ident)
+                if ident is not None and len(set(ids)) == world:
+                    data_group = dist.new_group(backend="nccl")
+                    backend = "nccl"
+                else:
+                    backend = "gloo"
 
     scene = os.path.join(ROOT, "lego_rust")
     r = N.Renderer(dev_index)
@@ -210,7 +224,7 @@ def main():
                            skip_empty=args.skip_empty, skip_dead=args.skip_dead, device_out=frame.data_ptr(), stream=stream)
             return frame
         return N.render_image_distributed(r.coarse, r.fine, cam, args.fine, seed=args.seed, ssaa=args.ssaa, dtype=args.dtype,
-                                          skip_empty=args.skip_empty, skip_dead=args.skip_dead, return_tensor=True)
+                                          skip_empty=args.skip_empty, skip_dead=args.skip_dead, group=data_group, return_tensor=True)
 
     def fence():
         if use_dist:
@@ -370,8 +384,8 @@ def main():
         line = {  # noqa: E501
             "metric": "rays/sec, lego 800x800 (64 coarse + 128 fine samples per ray)", "value": value, "unit": "rays/s",
             "n_gpus": world, "ranks": dist.get_world_size() if use_dist else 1,
-            "backend": ((dist.get_backend() + (" (RCCL over xGMI)" if dist.get_backend() == "nccl" else
-                                                f" (REHEARSAL: {world} ranks share {n_visible} GPU(s); the collective runs on host copies)"))
+            "backend": ((backend + (" (RCCL over xGMI)" if backend == "nccl" else
+                                    f" (REHEARSAL: {world} ranks share {n_visible} GPU(s); the collective runs on host copies)"))
                         if use_dist else "none (single process, no collective)"),
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
             "higher_is_better": True, "scaling": "weak" if weak else "strong", "vs_baseline": None,

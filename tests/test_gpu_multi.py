@@ -110,3 +110,17 @@ def test_bench_self_launches_two_ranks_on_this_gpu():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["ranks"] == 2 and d["backend"].startswith("gloo") and "REHEARSAL" in d["backend"]
     assert d["value"] > 0 and d["scaling"] == "strong" and d["config"]["rays_per_step"] == 96 * 80
+
+
+def test_bench_rccl_paths_at_world_size_one():
+    """The RCCL (torch "nccl") collective of bench.py's N > 1 path, driven at world size 1 on this box's one GPU: (a) the direct
+    init_process_group("nccl") the 8-GPU run takes, (b) the branch for launchers that give every rank ONE visible GPU -- identities
+    exchanged over gloo, then an RCCL sub-group for the data path."""
+    for extra_env in ({}, {"NERF_BENCH_BACKEND": ""}):
+        env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+        env.update(NERF_BENCH_FORCE_DIST="1", MASTER_PORT="29517", **extra_env)
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "1", "--width", "96",
+                            "--height", "80", "--no-extra", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, env=env)
+        assert p.returncode == 0, p.stderr[-2000:]
+        d = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][0])
+        assert d["ranks"] == 1 and d["backend"].startswith("nccl") and d["value"] > 0
