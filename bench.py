@@ -349,6 +349,26 @@ def main():
             "executed_fraction_colour_head": st.n_exec_colour / max(st.n_fine_points, 1),
             "device_ms": {"total": st.ms_total, "coarse_trunk_f32": st.ms_coarse_mlp, "fine_trunk_plus_colour_bf16x3": st.ms_fine_mlp, "other": st.ms_other}}
         r.kernel_time_query(reset=True)
+    # Reported separately, never part of `value`: BASELINE config C5's geometry on this one GPU -- 800x800 output, 2x2 SSAA
+    # (1600x1600 = 2.56 M rays), bf16 operands / f32 accumulate (PSNR-level parity: tests/test_gpu_frame_fixture.py).
+    extra_c5 = None
+    if world == 1 and args.dtype == "f32" and args.ssaa == 1 and not args.skip_empty and not args.skip_dead and not args.no_extra:
+        def c5_step(stats=False):
+            return N.render_image(r.coarse, r.fine, cam, args.fine, seed=args.seed, ssaa=2, dtype="bf16",
+                                  device_out=frame.data_ptr(), stream=stream, return_stats=stats)
+        c5_step(); c5_step(); torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        for _ in range(3):
+            c5_step()
+        torch.cuda.synchronize(dev)
+        ms = 1e3 * (time.perf_counter() - t1) / 3
+        st = c5_step(stats=True)
+        n_r = 4 * args.width * args.height
+        extra_c5 = {"workload": f"C5 on one GPU: {args.width}x{args.height} output, 2x2 SSAA = {n_r} rays, {args.coarse}+{args.fine} samples/ray, bf16 MLP",
+                    "rays_per_s": n_r / (ms * 1e-3), "ms_per_step": ms, "n_rays": st.n_rays,
+                    "whole_job_fraction_of_bf16_mfma_roofline": n_r / (ms * 1e-3) * N.flop_per_ray(args.coarse, args.fine) / (PEAK_BF16_MFMA_TFLOPS * 1e12),
+                    "device_ms": {"total": st.ms_total, "coarse": st.ms_coarse_mlp, "fine": st.ms_fine_mlp, "other": st.ms_other}}
+        r.kernel_time_query(reset=True)
     # The timed region leaves the frame in HBM (`value` never includes PCIe); the host-pointer entry point additionally pays
     # one D2H copy of the frame (BASELINE.md section 4 counts it on the GPU side): measured here, reported beside `value`.
     d2h_ms = None
@@ -381,6 +401,8 @@ def main():
         traffic, traffic_src = pmc_traffic_bytes("void nerf_mlp_kernel_bf16v2<true" if bf16 else
                                                  "void nerf_mlp_kernel_bf16x3<true" if x3 else
                                                  "void nerf_trunk_seq_kernel<true" if args.skip_dead else "void nerf_mlp_kernel<true")
+        if args.skip_dead and x3:
+            traffic, traffic_src = pmc_traffic_bytes("void nerf_trunk_seq_kernel_x3<true")
         line = {  # noqa: E501
             "metric": "rays/sec, lego 800x800 (64 coarse + 128 fine samples per ray)", "value": value, "unit": "rays/s",
             "n_gpus": world, "ranks": dist.get_world_size() if use_dist else 1,
@@ -408,7 +430,8 @@ def main():
                          "frac": ach / peak, "traffic": traffic,
                          "traffic_source": (f"HBM bytes per launch from the committed rocprofv3 PMC passes ({traffic_src}; 2 x FETCH_SIZE + WRITE_SIZE "
                                             "in separate --pmc runs), not re-measured in this run; algorithmic: 20 B/point") if traffic_src else None,
-                         "kernel": ("nerf_trunk_seq_kernel<EXPORT=true> (fine network, ray-sequential trunk; executed flops)" if dead_stats is not None else
+                         "kernel": (("nerf_trunk_seq_kernel_x3" if x3 else "nerf_trunk_seq_kernel") + "<EXPORT=true> (fine network, ray-sequential trunk; executed flops)"
+                                    if dead_stats is not None else
                                     ("nerf_mlp_kernel_bf16v2" if bf16 else "nerf_mlp_kernel_bf16x3" if x3 else "nerf_mlp_kernel") +
                                     "<FULL=true, MODE_RAYS> (fine network)"),
                          "launches": n_dom, "avg_launch_ms": ms_dom / max(n_dom, 1),
@@ -425,6 +448,8 @@ def main():
             line["extra_skip_empty"] = extra_skip
         if extra_dead:
             line["extra_skip_dead"] = extra_dead
+        if extra_c5:
+            line["extra_c5_bf16_ssaa2"] = extra_c5
         if world == 1 and not args.no_cpu_baseline and not bf16 and not x3:
             line["cpu_baseline"] = cpu_baseline(args.width, args.height, args.coarse, args.fine, args.seed, not args.no_cpu_reference_order)
         print(json.dumps(line), flush=True)
