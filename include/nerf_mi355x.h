@@ -164,8 +164,9 @@ int nerf_render_image_device(nerf_ctx *ctx, const nerf_camera *cam, const nerf_r
  *   NERF_GATHER_PEER  bands are copied GPU -> GPU over xGMI (hipMemcpyPeerAsync) into a frame on ctxs[0]'s device, then one D2H;
  *   NERF_GATHER_RCCL  ONE ncclAllGather of the bands (RCCL over xGMI; librccl is dlopen'ed on first use): the whole frame
  *                     ends up on every device, then one D2H from ctxs[0].  Needs distinct devices.
- * Synchronous.  per_ctx (n entries) may be NULL.  Several contexts may share a device (tests; no speed-up).  Not re-entrant
- * for the same contexts.  Errors of any band are reported on ctxs[0]. */
+ * Synchronous.  per_ctx (n entries) may be NULL.  Several contexts may share a device (tests; no speed-up).  Not re-entrant:
+ * calls that share a context -- or, with NERF_GATHER_RCCL, a device (the communicators are cached per device list) -- must not
+ * overlap.  Errors of any band are reported on ctxs[0]. */
 enum { NERF_GATHER_HOST = 0, NERF_GATHER_PEER = 1, NERF_GATHER_RCCL = 2 };
 int nerf_render_image_multi(nerf_ctx *const *ctxs, int n, const nerf_camera *cam, const nerf_render_opts *opts, int gather,
                             float *rgb_out, nerf_stats *per_ctx /* n entries or NULL */);

@@ -175,7 +175,7 @@ int nerf_render_image_multi(nerf_ctx *const *ctxs, int n, const nerf_camera *cam
     // its context's stream, then its share of the gather, and waits for its own stream only.
     float *d_frame0 = c0->d_out;
     const int dev0 = c0->device;
-    auto work = [&](int i) {
+    auto work_body = [&](int i) {
         Job &J = jobs[i];
         nerf_ctx *c = J.c;
         if (hipSetDevice(c->device) != hipSuccess) { J.rc = fail(c, NERF_ERR_HIP, "hipSetDevice failed"); return; }
@@ -199,13 +199,21 @@ int nerf_render_image_multi(nerf_ctx *const *ctxs, int n, const nerf_camera *cam
         if (e == hipSuccess && gather != NERF_GATHER_RCCL) e = hipStreamSynchronize(c->stream);
         if (e != hipSuccess) J.rc = fail(c, NERF_ERR_HIP, std::string("band gather: ") + hipGetErrorString(e));
     };
+    auto work = [&](int i) { // nothing may escape a thread (std::terminate) or the C ABI
+        try { work_body(i); }
+        catch (const std::exception &e) { jobs[i].rc = fail(jobs[i].c, NERF_ERR_INVALID, std::string("internal error: ") + e.what()); }
+        catch (...) { jobs[i].rc = fail(jobs[i].c, NERF_ERR_INVALID, "internal error"); }
+    };
     if (n == 1) {
         DeviceGuard dg(c0->device);
         work(0);
     } else {
-        std::vector<std::thread> th;
-        for (int i = 0; i < n; ++i) th.emplace_back(work, i);
-        for (auto &t : th) t.join();
+        struct Joiner { // joins whatever was started, also when starting a later thread throws
+            std::vector<std::thread> th;
+            ~Joiner() { for (auto &t : th) if (t.joinable()) t.join(); }
+        } pool;
+        pool.th.reserve(n);
+        for (int i = 0; i < n; ++i) pool.th.emplace_back(work, i);
     }
     for (int i = 0; i < n; ++i)
         if (jobs[i].rc) { if (ctxs[i] != c0) c0->err = ctxs[i]->err; return fail(c0, jobs[i].rc, c0->err); }
