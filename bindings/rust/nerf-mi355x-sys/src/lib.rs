@@ -29,6 +29,7 @@ pub struct nerf_camera {
 pub const NERF_MLP_F32: i32 = 0;
 pub const NERF_MLP_BF16: i32 = 1;
 pub const NERF_MLP_BF16X3: i32 = 2;
+pub const NERF_MLP_F16X2: i32 = 3;
 
 #[repr(C)]
 #[derive(Clone, Copy, Debug, Default)]
@@ -98,6 +99,7 @@ extern "C" {
     pub fn nerf_debug_pack_network_dir(dir: *const c_char, wstream: *mut f32, wstream_cap: usize, small: *mut f32,
                                        small_cap: usize, wstream_len: *mut usize, small_len: *mut usize) -> c_int;
     pub fn nerf_debug_split_bf16x3(values: *const f32, n: usize, parts: *mut u16) -> c_int;
+    pub fn nerf_debug_split_f16x2(values: *const f32, n: usize, parts: *mut u16) -> c_int;
     pub fn nerf_debug_shader_clock_mhz(ctx: *mut nerf_ctx, mhz: *mut f64) -> c_int;
     pub fn nerf_forward_batch(ctx: *mut nerf_ctx, which: c_int, pts_soa: *const f32, dirs_aos: *const f32, n: usize,
                               rgb_aos: *mut f32, sigma: *mut f32) -> c_int;

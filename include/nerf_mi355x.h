@@ -43,7 +43,7 @@ typedef enum {
 } nerf_status;
 
 enum { NERF_NET_COARSE = 0, NERF_NET_FINE = 1 };
-enum { NERF_MLP_F32 = 0, NERF_MLP_BF16 = 1, NERF_MLP_BF16X3 = 2 };
+enum { NERF_MLP_F32 = 0, NERF_MLP_BF16 = 1, NERF_MLP_BF16X3 = 2, NERF_MLP_F16X2 = 3 };
 
 /* Mirrors `struct Camera` (src/lib.rs:197-211); samples_per_ray lives in nerf_render_opts.n_coarse.
  * alpha_* are the half field-of-view angles (radians); dir/up need not be orthogonal (basis is rebuilt
@@ -70,12 +70,18 @@ typedef struct {
                            * activation is split into three bf16 parts (exact to 2^-27) and a product is the sum of the six
                            * significant bf16 x bf16 products, accumulated in f32.  In a hierarchical render the coarse
                            * (sampling) pass stays on the exact-f32 kernel so that the fine sample positions equal the f32
-                           * path's bit for bit; the fine (colour) pass runs in bf16x3.  Meets the f32 path's tolerances. */
+                           * path's bit for bit; the fine (colour) pass runs in bf16x3.  Meets the f32 path's tolerances.
+                           * NERF_MLP_F16X2 (3, opt-in): the cheaper sibling -- two f16 parts per operand (exact to 2^-22), three
+                           * products per f32 product; same f32 sampling pass, same tolerances (the error against float64 stays
+                           * at the f32 kernel's level: accumulation rounding dominates), half the matrix work of bf16x3.
+                           * Range: f16 overflows at 65 504 -- activations must stay below it (true for the lego networks inside
+                           * the scene and well beyond: validated for |p| <= 16; bf16x3 has no such limit); a network with a
+                           * weight beyond the f16 range makes this mode unavailable (NERF_ERR_STATE). */
     int32_t skip_empty;   /* ext: 1 = skip the colour head (bottleneck + viewdirs + rgb, 17 % of a full MLP
                            * evaluation) for every workgroup tile (128 samples in f32, 256 in bf16) whose densities are all 0.
                            * EXACT: such samples have alpha = 0 and weight 0, the image is bit-identical; only the work
                            * changes.  Default 0 so that timings are plain executed-FLOP figures. */
-    int32_t skip_dead;    /* ext (the rest of it; NERF_MLP_F32 and NERF_MLP_BF16X3): 1 = evaluate only what can reach a pixel.
+    int32_t skip_dead;    /* ext (the rest of it; NERF_MLP_F32, NERF_MLP_BF16X3, NERF_MLP_F16X2): 1 = evaluate only what can reach a pixel.
                            * Rays are walked front to back in chunks of 32 samples; a ray is retired at the reference's
                            * T < 1e-4 cut (src/lib.rs:276-279: every later weight is exactly 0), and the colour head runs only
                            * on the samples whose weight is > 0 (compacted through HBM, second launch).  EXACT: the image is
@@ -131,6 +137,8 @@ int nerf_debug_pack_network_dir(const char *dir, float *wstream, size_t wstream_
 /* Diagnostic: the three bf16 parts (raw bit patterns) the NERF_MLP_BF16X3 packer stores for each of n f32 weights:
  * parts[3 i + k], k = 0..2, with v = p0 + p1 + p2 up to 2^-27 |v|.  Host-only. */
 int nerf_debug_split_bf16x3(const float *values, size_t n, uint16_t *parts /* 3 n */);
+/* The same for the NERF_MLP_F16X2 packer: two f16 parts (IEEE binary16 bit patterns), v = p0 + p1 up to 2^-22 |v|.  Host-only. */
+int nerf_debug_split_f16x2(const float *values, size_t n, uint16_t *parts /* 2 n */);
 
 /* ---- S2: Network::forward_batch (src/network.rs:197-237) -------------------------------------------------- */
 /* host pointers, synchronous.  n == 0 is a no-op (src/network.rs:199-201).
@@ -140,7 +148,7 @@ int nerf_debug_split_bf16x3(const float *values, size_t n, uint16_t *parts /* 3 
  * n is limited to INT32_MAX minus one grid stride of tiles (~2.1e9 points); larger batches return NERF_ERR_INVALID. */
 int nerf_forward_batch(nerf_ctx *ctx, int which, const float *pts_soa /*3 x n*/, const float *dirs_aos /*n x 3*/,
                        size_t n, float *rgb_aos /*n x 3*/, float *sigma /*n*/);
-/* same with an explicit MLP arithmetic (NERF_MLP_F32 / NERF_MLP_BF16 / NERF_MLP_BF16X3) */
+/* same with an explicit MLP arithmetic (NERF_MLP_F32 / NERF_MLP_BF16 / NERF_MLP_BF16X3 / NERF_MLP_F16X2) */
 int nerf_forward_batch_ex(nerf_ctx *ctx, int which, int mlp_dtype, const float *pts_soa, const float *dirs_aos, size_t n,
                           float *rgb_aos, float *sigma);
 /* device pointers, asynchronous on `stream` (a hipStream_t passed as void*; NULL = default stream) */

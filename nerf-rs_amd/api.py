@@ -18,7 +18,7 @@ from ._lib import CCamera, COpts, CStats, NerfError, check, f32p, u32p
 
 NET_COARSE, NET_FINE = 0, 1
 MLP_F32, MLP_BF16 = 0, 1
-_DTYPES = {"f32": 0, "float32": 0, 0: 0, "bf16": 1, "bfloat16": 1, 1: 1, "bf16x3": 2, 2: 2}
+_DTYPES = {"f32": 0, "float32": 0, 0: 0, "bf16": 1, "bfloat16": 1, 1: 1, "bf16x3": 2, 2: 2, "f16x2": 3, 3: 3}
 
 
 def _f32(a):

@@ -243,6 +243,32 @@ void x3_stream_from_v1order(const std::vector<float> &v1f, std::vector<uint16_t>
         }
 }
 
+// w = w1 + w2 (+ at most 2^-22 |w|): w1 = f16(w), w2 = f16(w - w1), round to nearest even; the subtraction is exact in f32.
+// Values beyond the f16 range (|w| > 65504) would become infinite: the loader rejects such networks for this arithmetic.
+void split_f16x2(float v, uint16_t out[2]) {
+    const _Float16 h = (_Float16)v;
+    const _Float16 l = (_Float16)(v - (float)h);
+    memcpy(&out[0], &h, 2);
+    memcpy(&out[1], &l, 2);
+}
+
+// f16x2 stream: every piece of the v1 order followed by the piece of the second part of the same weights
+bool x2_stream_from_v1order(const std::vector<float> &v1f, std::vector<uint16_t> &ws) {
+    const size_t n_pieces = v1f.size() / 512;
+    ws.assign(n_pieces * 2 * 512, (uint16_t)0);
+    bool in_range = true;
+    for (size_t pc = 0; pc < n_pieces; ++pc)
+        for (int e = 0; e < 512; ++e) {
+            const float v = v1f[pc * 512 + e];
+            if (!(fabsf(v) <= 65504.0f)) in_range = false;
+            uint16_t parts[2];
+            split_f16x2(v, parts);
+            ws[(pc * 2 + 0) * 512 + e] = parts[0];
+            ws[(pc * 2 + 1) * 512 + e] = parts[1];
+        }
+    return in_range;
+}
+
 // ------------------------------------------------------------------------------------------------
 // Camera (reference src/lib.rs:614-645, 213-231; src/vec3.rs:19-34)
 // ------------------------------------------------------------------------------------------------

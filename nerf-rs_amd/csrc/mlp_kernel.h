@@ -75,3 +75,9 @@ hipError_t nerf_colour_launch(const ColourArgs &a, int n_blocks, hipStream_t str
 hipError_t nerf_seq_x3_init();
 hipError_t nerf_trunk_seq_x3_launch(const SeqArgs &a, bool export_live, int n_blocks, hipStream_t stream);
 hipError_t nerf_colour_x3_launch(const ColourArgs &a, int n_blocks, hipStream_t stream);
+// f32 by two-way f16 split (mlp_kernel_f16x2.hip): a.wstream is the two-part f16 stream (mlp_layout.h kChunks*F16X2)
+hipError_t nerf_mlp_f16x2_init();
+hipError_t nerf_mlp_f16x2_launch(const MlpArgs &a, bool full, int n_blocks, hipStream_t stream);
+hipError_t nerf_seq_f16x2_init();
+hipError_t nerf_trunk_seq_f16x2_launch(const SeqArgs &a, bool export_live, int n_blocks, hipStream_t stream);
+hipError_t nerf_colour_f16x2_launch(const ColourArgs &a, int n_blocks, hipStream_t stream);

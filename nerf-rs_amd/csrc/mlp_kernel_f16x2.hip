@@ -1,0 +1,289 @@
+// mlp_kernel_f16x2.hip -- the fused NeRF MLP in "f32 by two-way f16 split" arithmetic (mlp_dtype = NERF_MLP_F16X2).
+//
+// The cheaper sibling of mlp_kernel_bf16x3.hip.  An f32 value is the sum of two f16 numbers up to 2^-22 relative: x = x1 + x2 with
+// x1 = f16(x), x2 = f16(x - x1) (the subtraction is exact in f32; f16 has an 11-bit significand).  A product w x is then
+//      (w2 x1 + w1 x2) + w1 x1 + O(2^-22 |w x|)
+// -- THREE f16 x f16 products, each formed exactly by v_mfma_f32_32x32x16_f16 and accumulated in f32, small terms first; the dropped
+// w2 x2 is 2^-22 of the product.  Three 32-cycle MFMAs replace the six of bf16x3 and the eight 64-cycle MFMAs of the f32 kernel
+// (5.3 x fewer matrix cycles per f32 FLOP).  What it gives up against bf16x3: two bits of operand precision (22 instead of 24 --
+// against fp64 the layer outputs stay at the f32 kernel's error level, because accumulation rounding dominates both) and RANGE:
+// f16 overflows at 65 504, so activations must stay below that (the lego networks: |activation| < 300 in the scene; see the domain
+// note in include/nerf_mi355x.h); subnormal f16 operands are honoured by the MFMA (MODE.fp16 denormals on, hipcc's default), so
+// small values lose nothing beyond the 2^-24 absolute floor of f16.
+//
+// Structure, stream order, register layouts, small parameters: exactly the bf16x3 kernel's, with two pieces per unit instead of
+// three (mlp_layout.h kChunkBytesF16X2): a unit = the (w1, w2) fragments of one 32 x 16 weight block = 2 KiB, a k-step of an 8-tile
+// layer = one 16-KiB chunk, each wave DMAs four 1-KiB pieces per chunk behind units 4..7.  Kernel bodies: mlp_split_kernels.hip.h.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <type_traits>
+
+#include "mlp_common.hip.h"
+#include "mlp_kernel.h"
+#include "mlp_layout.h"
+#include "mlp_seq_common.hip.h"
+
+using namespace nerfmlp;
+using namespace mlpdev;
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int kCB = kChunkBytesF16X2, kRS = kRingSlotsF16X2;
+#ifndef NERF_F16X2_AHEAD
+#define NERF_F16X2_AHEAD 2
+#endif
+constexpr int kAhead = NERF_F16X2_AHEAD; // operand prefetch distance in units (1..3); a unit is three MFMAs = 96 cycles
+
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F &&f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+// ---- weight-stream pipeline: 16-KiB chunks of eight 2-KiB units in an LDS ring filled by LDS-DMA, one s_waitcnt + s_barrier per
+// chunk at unit 4, operand fragments prefetched kAhead units ahead (the scheme of mlp_x3_pipe.hip.h with two pieces per unit)
+struct PipeH {
+    const LDS_AS char *rd_base;   // LDS address (incl. lane * 16) of the chunk the next prefetched unit lives in
+    const LDS_AS char *ring_lane;
+    uint32_t rd_slot_off;
+    u32x4 a[8];                   // A fragments (w1, w2) of four consecutive units (slot = unit & 3)
+    uint32_t ring_addr, wr_slot_off, next_off, stream_bytes;
+    const char *gbase, *cur_src;
+    uint32_t cur_dst, lane16;
+};
+
+template <int OFF>
+__device__ __forceinline__ void glds_piece_off(uint32_t lane16, const char *gsrc, uint32_t dst) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\t"
+                 "s_mov_b32 m0, %3\n\t"
+                 "s_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, %2 offset:%4\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(lane16), "s"(gsrc), "s"(dst), "n"(OFF)
+                 : "memory");
+}
+
+__device__ __forceinline__ void pipe_next_chunk(PipeH &P) {
+    uint32_t off = P.next_off, slot = P.wr_slot_off;
+    asm volatile("" : "+s"(off), "+s"(slot));
+    P.cur_src = P.gbase + off;
+    P.cur_dst = P.ring_addr + slot;
+    off += kCB;
+    P.next_off = (off == P.stream_bytes) ? 0u : off;
+    slot += kCB;
+    P.wr_slot_off = (slot == kRS * kCB) ? 0u : slot;
+}
+
+// (Re)start at chunk 0 in the state a steady-state run is in there: chunks 0 .. kRS - 2 issued (every wave its four pieces of
+// each) and landed, unit 0 .. kAhead - 1 prefetched.  The caller guarantees that no wave still reads the ring.
+__device__ __forceinline__ void pipe_start(PipeH &P) {
+    P.next_off = 0;
+    P.wr_slot_off = 0;
+#pragma unroll
+    for (int c = 0; c < kRS - 1; ++c) {
+        pipe_next_chunk(P);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) glds_piece(P.lane16, P.cur_src + i * 1024, P.cur_dst + i * 1024);
+    }
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    P.rd_slot_off = 0;
+    P.rd_base = P.ring_lane;
+#pragma unroll
+    for (int s = 0; s < 2 * kAhead; ++s) P.a[s] = *(const LDS_AS u32x4 *)(P.rd_base + s * 1024);
+}
+
+// Unit U (0..7 within its chunk) begins: hand out its two A fragments.  Unit 4: the chunk after this one must have landed (every
+// wave waits for its own pieces, then the barrier) and the slot of the previous chunk is refilled with chunk c + kRS - 1.
+template <int U>
+__device__ __forceinline__ void pipe_take(PipeH &P, f16x8 &a1, f16x8 &a2) {
+    if constexpr (U == 4) {
+        asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(4 * (kRS - 3)) : "memory");
+        pipe_next_chunk(P);
+    }
+    constexpr int cur = (U & 3) * 2;
+    a1 = __builtin_bit_cast(f16x8, P.a[cur]); a2 = __builtin_bit_cast(f16x8, P.a[cur + 1]);
+}
+
+template <int U>
+__device__ __forceinline__ void pipe_prefetch(PipeH &P) {
+    constexpr int nxt = ((U + kAhead) & 3) * 2;
+    if constexpr (U + kAhead == 8) { // the unit to fetch opens the next chunk
+        uint32_t off = P.rd_slot_off + kCB;
+        off = (off == kRS * kCB) ? 0u : off;
+        P.rd_slot_off = off;
+        P.rd_base = P.ring_lane + off;
+    }
+    constexpr int nu = (U + kAhead) & 7;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) P.a[nxt + s] = *(const LDS_AS u32x4 *)(P.rd_base + (2 * nu + s) * 1024);
+}
+
+// the LDS-DMA piece issued behind unit U: the four pieces of the chunk selected at the last sync go out behind units 4..7
+template <int U>
+__device__ __forceinline__ void pipe_dma(PipeH &P) {
+    if constexpr (U >= 4) glds_piece_off<(U - 4) * 1024>(P.lane16, P.cur_src, P.cur_dst);
+}
+
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
+
+struct B2 { u32x4 h, l; }; // the two f16x8 fragments of one k-step's B operand
+
+// Splitting one pair of f32 values into packed (h, l) f16 pairs, in three stages of a few VALU instructions, one per MFMA gap.
+// x - f16(x) is exact in f32 (at most 13 significant bits are left).
+struct PrepState { f32x2 x; uint32_t h; };
+
+template <bool RELU, int KS, int Q, int STAGE>
+__device__ __forceinline__ void prep_stage(const f32x16 &in, B2 &b, PrepState &st) {
+    if constexpr (STAGE == 0) {
+        float x0 = in[8 * KS + 2 * Q], x1 = in[8 * KS + 2 * Q + 1];
+        asm volatile("" : "+v"(x0), "+v"(x1)); // keep the accumulator reads here (hipcc otherwise hoists a whole layer's)
+        if (RELU) { x0 = relu(x0); x1 = relu(x1); }
+        st.x = f32x2{x0, x1};
+    } else if constexpr (STAGE == 1) {
+        const f16x2 hh = __builtin_convertvector(st.x, f16x2);
+        st.h = __builtin_bit_cast(uint32_t, hh);
+        st.x = st.x - __builtin_convertvector(hh, f32x2);
+    } else {
+        b.h[Q] = st.h;
+        b.l[Q] = __builtin_bit_cast(uint32_t, __builtin_convertvector(st.x, f16x2));
+    }
+}
+
+template <bool RELU, int KS, int Q>
+__device__ __forceinline__ void prep_pair(const f32x16 &in, B2 &b) {
+    PrepState st;
+    prep_stage<RELU, KS, Q, 0>(in, b, st); prep_stage<RELU, KS, Q, 1>(in, b, st); prep_stage<RELU, KS, Q, 2>(in, b, st);
+}
+
+template <bool RELU, int KS>
+__device__ __forceinline__ void prep_all(const f32x16 &in, B2 &b) {
+    prep_pair<RELU, KS, 0>(in, b); prep_pair<RELU, KS, 1>(in, b); prep_pair<RELU, KS, 2>(in, b); prep_pair<RELU, KS, 3>(in, b);
+}
+
+#define X2_PIN() __builtin_amdgcn_sched_barrier(0)
+
+// One k-step: NT units with the prepared B `bc`.  A unit = the three products of one 32 x 16 weight block, small terms first, on
+// one accumulator chain; the other work rides in its MFMA gaps: the next unit's two ds_reads and the LDS-DMA piece behind MFMA 1,
+// and behind MFMAs 1..3 the three stages of splitting one pair of the NEXT k-step's B operand (pair q in unit 2 q of an 8-tile
+// layer, unit q of viewdirs).
+template <int NT, int U0, bool HAS_NEXT, bool NRELU, int NKS>
+__device__ __forceinline__ void k_step(f32x16 (&out)[8], const B2 &bc, const f32x16 &nin, B2 &bn, PipeH &P) {
+    const f16x8 b1 = __builtin_bit_cast(f16x8, bc.h), b2 = __builtin_bit_cast(f16x8, bc.l);
+    static_for<0, NT>([&](auto nt_c) {
+        constexpr int nt = decltype(nt_c)::value;
+        constexpr int U = U0 + nt;
+        constexpr bool prep = HAS_NEXT && (NT == 4 || (nt & 1) == 0);
+        constexpr int Q = NT == 4 ? nt : nt / 2;
+        f16x8 a1, a2;
+        PrepState st;
+        pipe_take<U>(P, a1, a2);
+        X2_PIN();
+        out[nt] = MFMA16(a2, b1, out[nt]);
+        X2_PIN();
+        pipe_prefetch<U>(P);
+        pipe_dma<U>(P);
+        if constexpr (prep) prep_stage<NRELU, NKS, Q, 0>(nin, bn, st);
+        X2_PIN();
+        out[nt] = MFMA16(a1, b2, out[nt]);
+        X2_PIN();
+        if constexpr (prep) prep_stage<NRELU, NKS, Q, 1>(nin, bn, st);
+        X2_PIN();
+        out[nt] = MFMA16(a1, b1, out[nt]);
+        X2_PIN();
+        if constexpr (prep) prep_stage<NRELU, NKS, Q, 2>(nin, bn, st);
+        X2_PIN();
+    });
+}
+
+// One input tile (two k-steps) of a layer with NT output tiles; see mlp_kernel_bf16x3.hip.
+template <int NT, bool RELU, bool ACC_IN, bool HAS_NEXT, bool NRELU, bool NACC_IN>
+__device__ __forceinline__ void tile_steps(f32x16 &in, f32x16 &nin, f32x16 (&out)[8], B2 &b, PipeH &P) {
+    if constexpr (ACC_IN) asm volatile("" : "+a"(in));
+    B2 b1;
+    k_step<NT, 0, true, RELU, 1>(out, b, in, b1, P);
+    if constexpr (HAS_NEXT && NACC_IN) asm volatile("" : "+a"(nin));
+    k_step<NT, (NT == 8 ? 0 : 4), HAS_NEXT, NRELU, 0>(out, b1, nin, b, P);
+    if constexpr (NT == 8)
+        asm volatile("" : "+a"(out[0]), "+a"(out[1]), "+a"(out[2]), "+a"(out[3]), "+a"(out[4]), "+a"(out[5]), "+a"(out[6]), "+a"(out[7]));
+    else
+        asm volatile("" : "+a"(out[0]), "+a"(out[1]), "+a"(out[2]), "+a"(out[3]));
+}
+
+template <int NT>
+__device__ __forceinline__ void load_bias(f32x16 (&out)[8], const LDS_AS float *bias, int h) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const LDS_AS f32x4 *b = (const LDS_AS f32x4 *)(bias + (nt * 2 + h) * 16);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 v = b[q];
+            out[nt][4 * q + 0] = v[0]; out[nt][4 * q + 1] = v[1]; out[nt][4 * q + 2] = v[2]; out[nt][4 * q + 3] = v[3];
+        }
+    }
+}
+
+template <int NT, bool RELU>
+__device__ __forceinline__ void eight_tiles(f32x16 (&in)[8], f32x16 (&out)[8], B2 &b, PipeH &P) {
+    tile_steps<NT, RELU, true, true, RELU, true>(in[0], in[1], out, b, P);
+    tile_steps<NT, RELU, true, true, RELU, true>(in[1], in[2], out, b, P);
+    tile_steps<NT, RELU, true, true, RELU, true>(in[2], in[3], out, b, P);
+    tile_steps<NT, RELU, true, true, RELU, true>(in[3], in[4], out, b, P);
+    tile_steps<NT, RELU, true, true, RELU, true>(in[4], in[5], out, b, P);
+    tile_steps<NT, RELU, true, true, RELU, true>(in[5], in[6], out, b, P);
+    tile_steps<NT, RELU, true, true, RELU, true>(in[6], in[7], out, b, P);
+}
+
+template <bool RELU>
+__device__ __forceinline__ void hidden_layer(f32x16 (&in)[8], f32x16 (&out)[8], const LDS_AS float *bias, PipeH &P, int h) {
+    load_bias<8>(out, bias, h);
+    B2 b;
+    asm volatile("" : "+a"(in[0]));
+    prep_all<RELU, 0>(in[0], b);
+    eight_tiles<8, RELU>(in, out, b, P);
+    tile_steps<8, RELU, true, false, false, false>(in[7], in[7], out, b, P);
+}
+
+__device__ __forceinline__ float alpha_head(const f32x16 (&Y)[8], const LDS_AS float *small, int h) {
+    const LDS_AS f32x4 *w = (const LDS_AS f32x4 *)(small + kAlphaWOff + h * 128);
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float x0 = Y[t][4 * q + 0], x1 = Y[t][4 * q + 1], x2 = Y[t][4 * q + 2], x3 = Y[t][4 * q + 3];
+            asm volatile("" : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3));
+            const f32x4 wv = w[t * 4 + q];
+            a0 = fmaf(wv[0], relu(x0), a0);
+            a1 = fmaf(wv[1], relu(x1), a1);
+            a2 = fmaf(wv[2], relu(x2), a2);
+            a3 = fmaf(wv[3], relu(x3), a3);
+        }
+    }
+    return fmaxf(xhalf_sum((a0 + a1) + (a2 + a3)) + small[kMiscOff + 0], 0.f);
+}
+
+using PipeS = PipeH;
+using BS = B2;
+constexpr int kSplitChunksSigma = kChunksSigmaF16X2, kSplitChunksFull = kChunksFullF16X2, kSplitLdsBytes = kLdsBytesF16X2;
+constexpr int kSplitWaveBytes = 4096; // a wave DMAs four 1-KiB pieces of every 16-KiB chunk
+
+} // namespace
+
+#define SPLIT_KERNEL_FUSED nerf_mlp_kernel_f16x2
+#define SPLIT_KERNEL_TRUNK nerf_trunk_seq_kernel_f16x2
+#define SPLIT_KERNEL_COLOUR nerf_colour_kernel_f16x2
+#define SPLIT_FN_INIT nerf_mlp_f16x2_init
+#define SPLIT_FN_LAUNCH nerf_mlp_f16x2_launch
+#define SPLIT_FN_SEQ_INIT nerf_seq_f16x2_init
+#define SPLIT_FN_TRUNK_LAUNCH nerf_trunk_seq_f16x2_launch
+#define SPLIT_FN_COLOUR_LAUNCH nerf_colour_f16x2_launch
+#include "mlp_split_kernels.hip.h"

@@ -86,6 +86,18 @@ constexpr int kChunksFullX3 = kChunksSigmaX3 + 16 + 9;        // + bottleneck + 
 constexpr int kLdsBytesX3 = kRingSlotsX3 * kChunkBytesX3 + kSmallBytes;
 constexpr int kPiecesV1 = 8 * (4 + 4 * 16 + 20 + 3 * 16) + 4 * 18;  // 1160 pieces of the first bf16 design, without its padding
 
+// ---- f16x2 stream (mlp_kernel_f16x2.hip, f32 by two-way f16 split): the x3 stream's units with two pieces (the f16 parts w1, w2 of
+// the same 32 x 16 weight block) instead of three: a unit = 2 KiB, a k-step of an 8-tile layer = 16 KiB = one chunk, a k-step of
+// viewdirs half a chunk; the same chunk counts as the x3 stream.
+constexpr int kChunkBytesF16X2 = 16384;
+#ifndef NERF_F16X2_RING_SLOTS
+#define NERF_F16X2_RING_SLOTS 4
+#endif
+constexpr int kRingSlotsF16X2 = NERF_F16X2_RING_SLOTS; // 3..6; a chunk lasts only 8 units x 3 MFMAs x 32 cycles = 0.35 us
+constexpr int kChunksSigmaF16X2 = kChunksSigmaX3;
+constexpr int kChunksFullF16X2 = kChunksFullX3;
+constexpr int kLdsBytesF16X2 = kRingSlotsF16X2 * kChunkBytesF16X2 + kSmallBytes;
+
 // feature held by register r (0..15) of a tile on lane-half h, relative to the tile's first feature
 constexpr int regFeature(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 

@@ -1,0 +1,268 @@
+// mlp_split_kernels.hip.h -- the kernel bodies shared by the "f32 by operand splitting" arithmetics: bf16x3
+// (mlp_kernel_bf16x3.hip: three bf16 parts, six products) and f16x2 (mlp_kernel_f16x2.hip: two f16 parts, three products).
+// Textually included at the end of each of those files, after the file has defined, in an anonymous namespace, its
+// primitives -- PipeS (weight-stream pipeline) with pipe_start(), BS (split B operand), prep_all, tile_steps, eight_tiles,
+// hidden_layer, load_bias, alpha_head, kCB / kRS, kSplitChunksSigma / kSplitChunksFull, kSplitLdsBytes, kSplitWaveBytes --
+// and the SPLIT_* names of the kernels and host functions it instantiates here:
+//   SPLIT_KERNEL_FUSED<FULL, MODE>   the fused MLP (forward_batch + point fill), structure of mlp_kernel.hip
+//   SPLIT_KERNEL_TRUNK<EXPORT>       skip_dead: ray-sequential trunk     } scheme: mlp_kernel_seq.hip,
+//   SPLIT_KERNEL_COLOUR              skip_dead: compacted colour head    } shared half: mlp_seq_common.hip.h
+// The accumulator tiles have the f32 kernel's register layout (C/D of the 32x32 MFMAs), so the small parameters and the
+// exported h8 tiles are shared with it.
+
+template <bool FULL, int MODE>
+__global__ __launch_bounds__(256, 1) void SPLIT_KERNEL_FUSED(const MlpArgs A) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const LDS_AS char *lds = (const LDS_AS char *)smem;
+    const LDS_AS float *small = (const LDS_AS float *)(lds + kRS * kCB);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int p = lane & 31;
+    const int h = lane >> 5;
+
+    {
+        float *dst = (float *)(smem + kRS * kCB);
+        for (int i = tid; i < kSmallFloats; i += 256) dst[i] = A.small_params[i];
+    }
+    PipeS P;
+    P.lane16 = lane * 16;
+    P.ring_lane = lds + P.lane16;
+    P.ring_addr = (uint32_t)(uintptr_t)lds + wave * kSplitWaveBytes; // this wave's six pieces of a chunk
+    P.stream_bytes = (FULL ? kSplitChunksFull : kSplitChunksSigma) * kCB;
+    P.gbase = (const char *)A.wstream + wave * kSplitWaveBytes;
+    __syncthreads();
+    pipe_start(P);
+    uint64_t clk0 = 0, rt0 = 0;
+    if (A.clock_out) { clk0 = __builtin_amdgcn_s_memtime(); rt0 = __builtin_amdgcn_s_memrealtime(); }
+
+    const int n_tiles = (A.n_points + kPointsPerBlock - 1) / kPointsPerBlock;
+    RawIn nxt = load_raw<MODE>(A, blockIdx.x, wave, p);
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int i = tile * kPointsPerBlock + wave * kPointsPerWave + p;
+        const bool valid = i < A.n_points;
+        const RawIn in = nxt;
+        nxt = load_raw<MODE>(A, tile + gridDim.x, wave, p);
+        float px, py, pz;
+        point_of<MODE>(A, in, px, py, pz);
+        const float dx = in.dx, dy = in.dy, dz = in.dz;
+
+        f32x16 E[2];
+        encode_point<true>(px, py, pz, h, E);
+
+        f32x16 X[8], Y[8];
+        BS b;
+        load_bias<8>(X, small + kBiasOff + 0 * 256, h);          // dense0 (src/network.rs:204)
+        prep_all<false, 0>(E[0], b);
+        tile_steps<8, false, false, true, false, false>(E[0], E[1], X, b, P);
+        tile_steps<8, false, false, false, false, false>(E[1], E[1], X, b, P);
+        hidden_layer<true>(X, Y, small + kBiasOff + 1 * 256, P, h);
+        hidden_layer<true>(Y, X, small + kBiasOff + 2 * 256, P, h);
+        hidden_layer<true>(X, Y, small + kBiasOff + 3 * 256, P, h);
+        hidden_layer<true>(Y, X, small + kBiasOff + 4 * 256, P, h);
+        load_bias<8>(Y, small + kBiasOff + 5 * 256, h);          // dense5 on [encoding ; h4] (:209-210)
+        prep_all<false, 0>(E[0], b);
+        tile_steps<8, false, false, true, false, false>(E[0], E[1], Y, b, P);
+        tile_steps<8, false, false, true, true, true>(E[1], X[0], Y, b, P);
+        eight_tiles<8, true>(X, Y, b, P);
+        tile_steps<8, true, true, false, false, false>(X[7], X[7], Y, b, P);
+        hidden_layer<true>(Y, X, small + kBiasOff + 6 * 256, P, h);
+        hidden_layer<true>(X, Y, small + kBiasOff + 7 * 256, P, h);
+
+        const float sigma = alpha_head(Y, small, h);
+        if (valid && h == 0) A.sigma_out[i] = sigma;
+
+        if (FULL && A.skip_empty) { // exact empty-tile skip, see mlp_kernel.hip
+            LDS_AS int *vote = (LDS_AS int *)(lds + kRS * kCB) + kMiscOff + 8;
+            const bool any_wg = tile_has_density(vote, valid && sigma > 0.0f, wave, lane);
+            if (!any_wg) {
+                if (valid && h == 0) {
+                    A.rgb_out[3 * (size_t)i + 0] = 0.f; A.rgb_out[3 * (size_t)i + 1] = 0.f; A.rgb_out[3 * (size_t)i + 2] = 0.f;
+                }
+                if (A.skip_counter && tid == 0) atomicAdd(A.skip_counter, 1ull);
+                asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory"); // in-flight chunks landed; ring idle
+                pipe_start(P);
+                continue;
+            }
+        }
+
+        if (FULL) {
+            hidden_layer<true>(Y, X, small + kBiasOff + 8 * 256, P, h); // bottleneck: no activation on its output (:218)
+            f32x16 D;
+            encode_dir<true>(dx, dy, dz, h, D);
+            f32x16 (&V)[8] = Y;                                          // Y is dead after the bottleneck
+            load_bias<4>(V, small + kBiasViewOff, h);
+            asm volatile("" : "+a"(X[0]));
+            prep_all<false, 0>(X[0], b);
+            eight_tiles<4, false>(X, V, b, P);
+            tile_steps<4, false, true, true, false, false>(X[7], D, V, b, P);
+            tile_steps<4, false, false, false, false, false>(D, D, V, b, P);
+            float c[3];
+            rgb_head(V, small, h, c);
+            if (valid && h == 0) {
+                A.rgb_out[3 * (size_t)i + 0] = c[0];
+                A.rgb_out[3 * (size_t)i + 1] = c[1];
+                A.rgb_out[3 * (size_t)i + 2] = c[2];
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (A.clock_out && tid == 0) { // diagnostic: shader clock = d(memtime) / d(memrealtime) x 100 MHz
+        A.clock_out[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - clk0;
+        A.clock_out[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - rt0;
+    }
+}
+
+// ---- exact dead-sample skipping in this arithmetic (skip_dead with mlp_dtype = NERF_MLP_BF16X3; scheme: mlp_kernel_seq.hip,
+// shared half: mlp_seq_common.hip.h): the ray-sequential trunk and the compacted colour head with this file's layers.  The
+// accumulator tiles have the f32 kernel's register layout, so the exported h8 tiles and the small parameters are shared with it.
+namespace {
+__device__ __forceinline__ void pipe_begin(PipeS &P, const LDS_AS char *lds, int lane, int wave, const char *stream, int n_chunks) {
+    P.lane16 = lane * 16;
+    P.ring_lane = lds + P.lane16;
+    P.ring_addr = (uint32_t)(uintptr_t)lds + wave * kSplitWaveBytes;
+    P.stream_bytes = n_chunks * kCB;
+    P.gbase = stream + wave * kSplitWaveBytes;
+    __syncthreads();
+    pipe_start(P);
+}
+} // namespace
+
+template <bool EXPORT>
+__global__ __launch_bounds__(256, 1) void SPLIT_KERNEL_TRUNK(const SeqArgs A) {
+    using namespace mlpseq;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const LDS_AS char *lds = (const LDS_AS char *)smem;
+    const LDS_AS float *small = (const LDS_AS float *)(lds + kRS * kCB);
+    LDS_AS int *vote = (LDS_AS int *)(lds + kRS * kCB) + kMiscOff + 8;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int p = lane & 31;
+    const int h = lane >> 5;
+    {
+        float *dst = (float *)(smem + kRS * kCB);
+        for (int i = tid; i < kSmallFloats; i += 256) dst[i] = A.small_params[i];
+    }
+    PipeS P;
+    pipe_begin(P, lds, lane, wave, (const char *)A.wstream, kSplitChunksSigma);
+
+    RayWork W;
+    work_init(W, A);
+    while (work_acquire(W, A, vote, wave, lane)) {
+        const ChunkIn c = chunk_inputs(W, A, p);
+        f32x16 E[2];
+        encode_point<true>(c.px, c.py, c.pz, h, E);
+        f32x16 X[8], Y[8];
+        BS b;
+        load_bias<8>(X, small + kBiasOff + 0 * 256, h);
+        prep_all<false, 0>(E[0], b);
+        tile_steps<8, false, false, true, false, false>(E[0], E[1], X, b, P);
+        tile_steps<8, false, false, false, false, false>(E[1], E[1], X, b, P);
+        hidden_layer<true>(X, Y, small + kBiasOff + 1 * 256, P, h);
+        hidden_layer<true>(Y, X, small + kBiasOff + 2 * 256, P, h);
+        hidden_layer<true>(X, Y, small + kBiasOff + 3 * 256, P, h);
+        hidden_layer<true>(Y, X, small + kBiasOff + 4 * 256, P, h);
+        load_bias<8>(Y, small + kBiasOff + 5 * 256, h);
+        prep_all<false, 0>(E[0], b);
+        tile_steps<8, false, false, true, false, false>(E[0], E[1], Y, b, P);
+        tile_steps<8, false, false, true, true, true>(E[1], X[0], Y, b, P);
+        eight_tiles<8, true>(X, Y, b, P);
+        tile_steps<8, true, true, false, false, false>(X[7], X[7], Y, b, P);
+        hidden_layer<true>(Y, X, small + kBiasOff + 6 * 256, P, h);
+        hidden_layer<true>(X, Y, small + kBiasOff + 7 * 256, P, h);
+        const float sigma = alpha_head(Y, small, h);
+        chunk_finish<EXPORT>(W, A, c, sigma, Y, lane, p, h);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    work_done(W, A, lane);
+}
+
+__global__ __launch_bounds__(256, 1) void SPLIT_KERNEL_COLOUR(const ColourArgs A) {
+    using namespace mlpseq;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const LDS_AS char *lds = (const LDS_AS char *)smem;
+    const LDS_AS float *small = (const LDS_AS float *)(lds + kRS * kCB);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5;
+    {
+        float *dst = (float *)(smem + kRS * kCB);
+        for (int i = tid; i < kSmallFloats; i += 256) dst[i] = A.small_params[i];
+    }
+    PipeS P;
+    pipe_begin(P, lds, lane, wave, (const char *)A.wstream + (size_t)kSplitChunksSigma * kCB, kSplitChunksFull - kSplitChunksSigma);
+
+    unsigned n_live;
+    const int n_tiles = colour_tiles(A, &n_live);
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        f32x16 X[8], Y[8];
+        const ColourIn c = colour_inputs(A, n_live, tile, wave, lane, Y);
+        hidden_layer<true>(Y, X, small + kBiasOff + 8 * 256, P, h); // bottleneck
+        f32x16 D;
+        encode_dir<true>(c.dx, c.dy, c.dz, h, D);
+        f32x16 (&V)[8] = Y;
+        load_bias<4>(V, small + kBiasViewOff, h);
+        BS b;
+        asm volatile("" : "+a"(X[0]));
+        prep_all<false, 0>(X[0], b);
+        eight_tiles<4, false>(X, V, b, P);
+        tile_steps<4, false, true, true, false, false>(X[7], D, V, b, P);
+        tile_steps<4, false, false, false, false, false>(D, D, V, b, P);
+        float rgb[3];
+        rgb_head(V, small, h, rgb);
+        colour_store(A, c, rgb, h);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+hipError_t SPLIT_FN_SEQ_INIT() {
+    const void *ks[3] = {(const void *)SPLIT_KERNEL_TRUNK<true>, (const void *)SPLIT_KERNEL_TRUNK<false>, (const void *)SPLIT_KERNEL_COLOUR};
+    for (int i = 0; i < 3; ++i) {
+        hipError_t e = hipFuncSetAttribute(ks[i], hipFuncAttributeMaxDynamicSharedMemorySize, kSplitLdsBytes);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
+hipError_t SPLIT_FN_TRUNK_LAUNCH(const SeqArgs &a, bool export_live, int n_blocks, hipStream_t stream) {
+    if (a.n_rays <= 0 || a.samples_per_ray <= 0) return hipSuccess;
+    n_blocks = mlpseq::trunk_blocks(a, n_blocks);
+    if (export_live) hipLaunchKernelGGL(SPLIT_KERNEL_TRUNK<true>, dim3(n_blocks), dim3(256), kSplitLdsBytes, stream, a);
+    else hipLaunchKernelGGL(SPLIT_KERNEL_TRUNK<false>, dim3(n_blocks), dim3(256), kSplitLdsBytes, stream, a);
+    return hipGetLastError();
+}
+
+hipError_t SPLIT_FN_COLOUR_LAUNCH(const ColourArgs &a, int n_blocks, hipStream_t stream) {
+    if (n_blocks < 1) n_blocks = 1;
+    hipLaunchKernelGGL(SPLIT_KERNEL_COLOUR, dim3(n_blocks), dim3(256), kSplitLdsBytes, stream, a);
+    return hipGetLastError();
+}
+
+template <bool FULL, int MODE>
+static hipError_t launch_t(const MlpArgs &a, int n_blocks, hipStream_t stream) {
+    hipLaunchKernelGGL((SPLIT_KERNEL_FUSED<FULL, MODE>), dim3(n_blocks), dim3(256), kSplitLdsBytes, stream, a);
+    return hipGetLastError();
+}
+
+hipError_t SPLIT_FN_INIT() {
+    const void *ks[4] = {(const void *)SPLIT_KERNEL_FUSED<true, MLP_MODE_POINTS>, (const void *)SPLIT_KERNEL_FUSED<false, MLP_MODE_POINTS>,
+                         (const void *)SPLIT_KERNEL_FUSED<true, MLP_MODE_RAYS>, (const void *)SPLIT_KERNEL_FUSED<false, MLP_MODE_RAYS>};
+    for (int i = 0; i < 4; ++i) {
+        hipError_t e = hipFuncSetAttribute(ks[i], hipFuncAttributeMaxDynamicSharedMemorySize, kSplitLdsBytes);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
+hipError_t SPLIT_FN_LAUNCH(const MlpArgs &a, bool full, int n_blocks, hipStream_t stream) {
+    if (a.n_points <= 0) return hipSuccess;
+    const int n_tiles = (a.n_points + kPointsPerBlock - 1) / kPointsPerBlock;
+    if (n_blocks > n_tiles) n_blocks = n_tiles;
+    if (n_blocks < 1) n_blocks = 1;
+    if (a.mode == MLP_MODE_POINTS)
+        return full ? launch_t<true, MLP_MODE_POINTS>(a, n_blocks, stream) : launch_t<false, MLP_MODE_POINTS>(a, n_blocks, stream);
+    return full ? launch_t<true, MLP_MODE_RAYS>(a, n_blocks, stream) : launch_t<false, MLP_MODE_RAYS>(a, n_blocks, stream);
+}

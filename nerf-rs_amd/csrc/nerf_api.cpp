@@ -97,14 +97,17 @@ int ensure_workspace(nerf_ctx *c, size_t rays, size_t nc, size_t m) {
 int upload_packed(nerf_ctx *c, int which, const std::vector<float> &ws, const std::vector<float> &sm);
 
 // weight stream + launcher of the selected arithmetic
-static bool valid_dtype(int d) { return d == NERF_MLP_F32 || d == NERF_MLP_BF16 || d == NERF_MLP_BF16X3; }
+static bool valid_dtype(int d) { return d == NERF_MLP_F32 || d == NERF_MLP_BF16 || d == NERF_MLP_BF16X3 || d == NERF_MLP_F16X2; }
+static bool split_dtype(int d) { return d == NERF_MLP_BF16X3 || d == NERF_MLP_F16X2; } // f32-accurate operand-splitting arithmetics
 static const float *stream_of(const DevNet &n, int dtype) {
     if (dtype == NERF_MLP_BF16X3) return (const float *)n.wstream_x3;
+    if (dtype == NERF_MLP_F16X2) return (const float *)n.wstream_x2;
     return dtype == NERF_MLP_F32 ? n.wstream : (const float *)n.wstream_bf16v2;
 }
 static hipError_t launch_mlp(const nerf_ctx *c, int dtype, const MlpArgs &a, bool full, hipStream_t st) {
     if (dtype == NERF_MLP_F32) return nerf_mlp_launch(a, full, c->n_cus, st);
     if (dtype == NERF_MLP_BF16X3) return nerf_mlp_bf16x3_launch(a, full, c->n_cus, st);
+    if (dtype == NERF_MLP_F16X2) return nerf_mlp_f16x2_launch(a, full, c->n_cus, st);
     return nerf_mlp_bf16v2_launch(a, full, c->n_cus, st);
 }
 
@@ -144,6 +147,15 @@ int upload_bf16_family(nerf_ctx *c, int which, const std::vector<float> &v1f) {
     HIP_TRY(c, hipMemcpy(d.wstream_bf16v2, v2.data(), v2.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
     if (!d.wstream_x3) HIP_TRY(c, hipMalloc((void **)&d.wstream_x3, x3.size() * sizeof(uint16_t)));
     HIP_TRY(c, hipMemcpy(d.wstream_x3, x3.data(), x3.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    std::vector<uint16_t> x2;
+    if (x2_stream_from_v1order(v1f, x2)) { // every weight inside the f16 range (the lego networks: |w| <= 8.3)
+        if (x2.size() != (size_t)nerfmlp::kChunksFullF16X2 * nerfmlp::kChunkBytesF16X2 / 2) return fail(c, NERF_ERR_SHAPE, "internal: f16x2 stream size");
+        if (!d.wstream_x2) HIP_TRY(c, hipMalloc((void **)&d.wstream_x2, x2.size() * sizeof(uint16_t)));
+        HIP_TRY(c, hipMemcpy(d.wstream_x2, x2.data(), x2.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    } else if (d.wstream_x2) { // a reload with out-of-range weights: NERF_MLP_F16X2 becomes unavailable for this network
+        HIP_TRY(c, hipFree(d.wstream_x2));
+        d.wstream_x2 = nullptr;
+    }
     return NERF_OK;
 }
 
@@ -241,19 +253,21 @@ int nerfint::render_device(nerf_ctx *c, const nerf_camera *cam, const nerf_rende
     if (o->n_coarse <= 0) return fail(c, NERF_ERR_INVALID, "coarse samples per ray must be greater than 0"); // src/lib.rs:483-486
     if (o->n_fine < 0) return fail(c, NERF_ERR_INVALID, "fine samples per ray must be >= 0");
     for (int r : o->reserved) if (r != 0) return fail(c, NERF_ERR_INVALID, "reserved option fields must be 0");
-    if (!valid_dtype(o->mlp_dtype)) return fail(c, NERF_ERR_INVALID, "mlp_dtype must be NERF_MLP_F32, NERF_MLP_BF16 or NERF_MLP_BF16X3");
+    if (!valid_dtype(o->mlp_dtype)) return fail(c, NERF_ERR_INVALID, "mlp_dtype must be NERF_MLP_F32, NERF_MLP_BF16, NERF_MLP_BF16X3 or NERF_MLP_F16X2");
     const int dtype = o->mlp_dtype;
-    // bf16x3: the sampling pass (coarse sigma -> CDF -> fine sample positions) stays on the exact-f32 MFMA kernel, so the fine
+    // bf16x3 / f16x2: the sampling pass (coarse sigma -> CDF -> fine sample positions) stays on the exact-f32 MFMA kernel, so the fine
     // samples sit where the f32 path puts them bit for bit (a 1e-5 density difference can move a CDF entry across a fixed
     // uniform draw and relocate a sample -- a discontinuity, not an accuracy problem); only the colour-producing pass runs in
     // the three-way split arithmetic.
-    const int dtype_coarse = (dtype == NERF_MLP_BF16X3 && !o->coarse_only) ? NERF_MLP_F32 : dtype;
+    const int dtype_coarse = (split_dtype(dtype) && !o->coarse_only) ? NERF_MLP_F32 : dtype;
     if (o->skip_empty != 0 && o->skip_empty != 1) return fail(c, NERF_ERR_INVALID, "skip_empty must be 0 or 1");
     if (o->skip_dead != 0 && o->skip_dead != 1) return fail(c, NERF_ERR_INVALID, "skip_dead must be 0 or 1");
-    if (o->skip_dead && dtype == NERF_MLP_BF16) return fail(c, NERF_ERR_INVALID, "skip_dead is implemented for NERF_MLP_F32 and NERF_MLP_BF16X3 only");
+    if (o->skip_dead && dtype == NERF_MLP_BF16) return fail(c, NERF_ERR_INVALID, "skip_dead is implemented for NERF_MLP_F32, NERF_MLP_BF16X3 and NERF_MLP_F16X2 only");
     const bool seq = o->skip_dead != 0;
     if (!c->net[NERF_NET_COARSE].loaded) return fail(c, NERF_ERR_STATE, "coarse network not loaded");
     if (!o->coarse_only && !c->net[NERF_NET_FINE].loaded) return fail(c, NERF_ERR_STATE, "fine network not loaded");
+    if (dtype == NERF_MLP_F16X2 && !c->net[o->coarse_only ? NERF_NET_COARSE : NERF_NET_FINE].wstream_x2)
+        return fail(c, NERF_ERR_STATE, "NERF_MLP_F16X2 is unavailable for this network: a weight exceeds the f16 range");
     const int s = o->ssaa > 1 ? o->ssaa : 1;
     int x0 = 0, y0 = 0, cw = cam->nx, ch = cam->ny;
     if (o->crop_w > 0 || o->crop_h > 0) { x0 = o->crop_x0; y0 = o->crop_y0; cw = o->crop_w; ch = o->crop_h; }
@@ -322,7 +336,6 @@ int nerfint::render_device(nerf_ctx *c, const nerf_camera *cam, const nerf_rende
         }
         // skip_dead: one network over the rays of this pass as ray-sequential trunk [+ colour head on the live samples]
         auto seq_pass = [&](const DevNet &net, int dt, int spr, const float *t_in, float *sigma_out, float *rgb_out, int slot, int kind_trunk) -> int {
-            const bool x3 = dt == NERF_MLP_BF16X3;
             unsigned int *ctr = c->d_seq + 4 * (size_t)slot;
             HIP_TRY(c, hipMemsetAsync(sigma_out, 0, (size_t)n_rays * spr * sizeof(float), st)); // samples behind the cut stay 0
             if (rgb_out) HIP_TRY(c, hipMemsetAsync(rgb_out, 0, (size_t)n_rays * spr * 3 * sizeof(float), st)); // weight-0 samples: 0 * 0
@@ -334,7 +347,9 @@ int nerfint::render_device(nerf_ctx *c, const nerf_camera *cam, const nerf_rende
             q.stats = (unsigned long long *)(ctr + 2);
             {
                 Timed t(c, st, kind_trunk, (uint64_t)n_rays * spr, timing);
-                HIP_TRY(c, x3 ? nerf_trunk_seq_x3_launch(q, rgb_out != nullptr, c->n_cus, st) : nerf_trunk_seq_launch(q, rgb_out != nullptr, c->n_cus, st));
+                HIP_TRY(c, dt == NERF_MLP_BF16X3 ? nerf_trunk_seq_x3_launch(q, rgb_out != nullptr, c->n_cus, st)
+                           : dt == NERF_MLP_F16X2 ? nerf_trunk_seq_f16x2_launch(q, rgb_out != nullptr, c->n_cus, st)
+                                                  : nerf_trunk_seq_launch(q, rgb_out != nullptr, c->n_cus, st));
                 t.done(c->last_render);
             }
             if (rgb_out) {
@@ -342,7 +357,8 @@ int nerfint::render_device(nerf_ctx *c, const nerf_camera *cam, const nerf_rende
                 k.wstream = stream_of(net, dt); k.small_params = net.small; k.live_count = ctr + 1; k.h8 = c->d_h8; k.slot_point = c->d_slot_point;
                 k.ray_dirs = c->d_dirs; k.samples_per_ray = spr; k.rgb_out = rgb_out;
                 Timed t(c, st, 4, 0, timing);
-                HIP_TRY(c, x3 ? nerf_colour_x3_launch(k, c->n_cus, st) : nerf_colour_launch(k, c->n_cus, st));
+                HIP_TRY(c, dt == NERF_MLP_BF16X3 ? nerf_colour_x3_launch(k, c->n_cus, st)
+                           : dt == NERF_MLP_F16X2 ? nerf_colour_f16x2_launch(k, c->n_cus, st) : nerf_colour_launch(k, c->n_cus, st));
                 t.done(c->last_render);
             }
             return NERF_OK;
@@ -526,6 +542,8 @@ int nerf_create(int device_id, nerf_ctx **out) try {
             if (e1 == hipSuccess) e1 = nerf_mlp_bf16x3_init();
             if (e1 == hipSuccess) e1 = nerf_seq_init();
             if (e1 == hipSuccess) e1 = nerf_seq_x3_init();
+            if (e1 == hipSuccess) e1 = nerf_mlp_f16x2_init();
+            if (e1 == hipSuccess) e1 = nerf_seq_f16x2_init();
             e2 = e1 == hipSuccess ? sampling_init() : e1;
             if (e2 == hipSuccess) init_done.insert(device_id);
         }
@@ -544,7 +562,7 @@ void nerf_destroy(nerf_ctx *c) {
     if (!c) return;
     DeviceGuard dg(c->device);
     (void)hipDeviceSynchronize();
-    for (auto &n : c->net) { if (n.wstream) (void)hipFree(n.wstream); if (n.small) (void)hipFree(n.small); if (n.wstream_bf16v2) (void)hipFree(n.wstream_bf16v2); if (n.wstream_x3) (void)hipFree(n.wstream_x3); }
+    for (auto &n : c->net) { if (n.wstream) (void)hipFree(n.wstream); if (n.small) (void)hipFree(n.small); if (n.wstream_bf16v2) (void)hipFree(n.wstream_bf16v2); if (n.wstream_x3) (void)hipFree(n.wstream_x3); if (n.wstream_x2) (void)hipFree(n.wstream_x2); }
     float *ptrs[] = {c->d_dirs, c->d_tc, c->d_sc, c->d_rgbc, c->d_tf, c->d_sf, c->d_rgbf, c->d_rayfb, c->d_out};
     for (float *p : ptrs) if (p) (void)hipFree(p);
     if (c->d_scratch) (void)hipFree(c->d_scratch);
@@ -674,6 +692,12 @@ int nerf_debug_split_bf16x3(const float *values, size_t n, uint16_t *parts) try 
     return NERF_OK;
 } NERF_CATCH(nullptr)
 
+int nerf_debug_split_f16x2(const float *values, size_t n, uint16_t *parts) try {
+    if ((!values || !parts) && n) return fail(nullptr, NERF_ERR_INVALID, "NULL argument");
+    for (size_t i = 0; i < n; ++i) split_f16x2(values[i], parts + 2 * i);
+    return NERF_OK;
+} NERF_CATCH(nullptr)
+
 int nerf_debug_pack_network_dir(const char *dir, float *wstream, size_t wstream_cap, float *small, size_t small_cap,
                                 size_t *wstream_len, size_t *small_len) try {
     if (!dir) return fail(nullptr, NERF_ERR_INVALID, "dir is NULL");
@@ -715,7 +739,8 @@ static int forward_device(nerf_ctx *c, int which, int dtype, const float *d_pts,
     DeviceGuard dg(c->device);
     MlpArgs a{};
     a.mode = MLP_MODE_POINTS;
-    if (!valid_dtype(dtype)) return fail(c, NERF_ERR_INVALID, "mlp_dtype must be NERF_MLP_F32, NERF_MLP_BF16 or NERF_MLP_BF16X3");
+    if (!valid_dtype(dtype)) return fail(c, NERF_ERR_INVALID, "mlp_dtype must be NERF_MLP_F32, NERF_MLP_BF16, NERF_MLP_BF16X3 or NERF_MLP_F16X2");
+    if (dtype == NERF_MLP_F16X2 && !c->net[which].wstream_x2) return fail(c, NERF_ERR_STATE, "NERF_MLP_F16X2 is unavailable for this network: a weight exceeds the f16 range");
     a.wstream = stream_of(c->net[which], dtype); a.small_params = c->net[which].small;
     a.n_points = (int)n; a.pts_soa = d_pts; a.dirs_aos = d_dirs; a.sigma_out = d_sigma; a.rgb_out = d_rgb;
     HIP_TRY(c, launch_mlp(c, dtype, a, true, (hipStream_t)stream));

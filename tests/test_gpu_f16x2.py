@@ -1,0 +1,119 @@
+"""NERF_MLP_F16X2 (mlp_kernel_f16x2.hip): f32 by two-way f16 split -- every operand as the sum of two f16 parts (exact to 2^-22),
+every f32 product as the three significant f16 x f16 products on v_mfma_f32_32x32x16_f16, f32 accumulation.  Held to the SAME
+gates as the f32 MFMA kernel (and as bf16x3): the reference's 120 golden scalars, the oracle fixtures, live-oracle points, Gate 1 on
+crops and on the whole C3 frame, Gate 2; skip_dead must stay bit-exact on top of it.  Plus what is specific to f16: the range."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, SCENE, golden, psnr
+
+pytestmark = pytest.mark.gpu
+
+SIGMA_TOL, RGB_TOL = 1e-4, 2e-5
+
+
+def _close_mlp(rgb, sig, ergb, esig):
+    ds = np.abs(sig - esig) / (1 + np.abs(esig))
+    dr = np.abs(rgb - ergb)
+    assert ds.max() <= SIGMA_TOL, f"sigma rel err {ds.max()}"
+    assert dr.max() <= RGB_TOL, f"rgb abs err {dr.max()}"
+    return ds.max(), dr.max()
+
+
+def _gate1(img, ref):
+    d = np.abs(img - ref)
+    assert d.max() <= 5e-4 and d.mean() <= 1e-5 and psnr(img, ref) >= 90.0, (d.max(), d.mean(), psnr(img, ref))
+
+
+def test_f16x2_forward_meets_f32_tolerances(renderer, samples, oracle_nets):
+    origin = np.float32(samples["camera_origin"]); z = np.float32(samples["z_vals"])
+    n = 0
+    for ex in samples["examples"]:                       # the reference's own unit test (src/lib.rs:753-916)
+        rd = np.float32(ex["ray_d"])
+        pts = (origin[:, None] + rd[:, None] * z[None, :]).astype(np.float32)
+        dirs = np.tile(np.float32(ex["viewdir_unit"]), (5, 1))
+        for net, ks, kr in ((renderer.coarse, "coarse_sigma", "coarse_rgb"), (renderer.fine, "fine_sigma", "fine_rgb")):
+            rgb, sg = net.forward_batch(pts, dirs, dtype="f16x2")
+            _close_mlp(rgb, sg, np.float32(ex[kr]), np.float32(ex[ks]))
+            n += sg.size + rgb.size
+    assert n == 120
+    g = golden("forward_batch_4096.npz")
+    for name, net in (("coarse", renderer.coarse), ("fine", renderer.fine)):
+        rgb, sg = net.forward_batch(g["pts"], g["dirs"], dtype="f16x2")
+        e = _close_mlp(rgb, sg, g[f"{name}_rgb"], g[f"{name}_sigma"])
+        f = net.forward_batch(g["pts"], g["dirs"])
+        ef = _close_mlp(f[0], f[1], g[f"{name}_rgb"], g[f"{name}_sigma"])
+        print(f"\n{name}: error vs oracle (sigma rel, rgb abs)  f16x2 {e[0]:.2e} {e[1]:.2e} | f32 MFMA {ef[0]:.2e} {ef[1]:.2e}")
+        assert not np.array_equal(sg, f[1])               # it really is another arithmetic
+        for k in (1, 17, 33, 129, 1000):                  # ragged tiles; columns are independent
+            r2, s2 = net.forward_batch(g["pts"][:, :k], g["dirs"][:k], dtype="f16x2")
+            assert np.array_equal(s2, sg[:k]) and np.array_equal(r2, rgb[:k])
+    rng = np.random.default_rng(11)
+    k = 65536
+    pts = rng.uniform(-2.2, 2.2, size=(3, k)).astype(np.float32)
+    v = rng.normal(size=(k, 3)); dirs = (v / np.linalg.norm(v, axis=1, keepdims=True)).astype(np.float32)
+    for net, onet in ((renderer.coarse, oracle_nets[0]), (renderer.fine, oracle_nets[1])):
+        rgb, sg = net.forward_batch(pts, dirs, dtype="f16x2")
+        ergb, esg = onet.forward_batch(pts, dirs)
+        _close_mlp(rgb, sg, ergb, esg)
+
+
+def test_f16x2_range(renderer, oracle_nets):
+    """f16 overflows at 65 504.  Inside and well beyond the scene (|p| <= 16, sigma up to ~1000) the activations stay far below it
+    and the f32 tolerances hold; tiny inputs lose nothing (f16 subnormal operands are honoured by the MFMA)."""
+    rng = np.random.default_rng(3)
+    k = 16384
+    v = rng.normal(size=(k, 3)); dirs = (v / np.linalg.norm(v, axis=1, keepdims=True)).astype(np.float32)
+    for span in (1e-4, 16.0):
+        pts = rng.uniform(-span, span, size=(3, k)).astype(np.float32)
+        for net, onet in ((renderer.coarse, oracle_nets[0]), (renderer.fine, oracle_nets[1])):
+            rgb, sg = net.forward_batch(pts, dirs, dtype="f16x2")
+            ergb, esg = onet.forward_batch(pts, dirs)
+            ds = np.abs(sg - esg) / (1 + np.abs(esg))
+            print(f"\n|p| <= {span:g}: sigma rel err max {ds.max():.2e}, rgb abs err max {np.abs(rgb - ergb).max():.2e}, sigma max {esg.max():.0f}")
+            assert np.isfinite(sg).all() and np.isfinite(rgb).all()
+            assert ds.max() <= 3e-4 and np.abs(rgb - ergb).max() <= 1e-4
+
+
+def test_f16x2_render_gate1_and_skip_dead(renderer, native, samples):
+    cam = native.camera_from_samples(samples, 800, 800, 64)
+    g = golden("crop_c3_800_64_128.npz")
+    crop = tuple(int(v) for v in g["crop"])
+    img = native.render_image(renderer.coarse, renderer.fine, cam, 128, seed=0, crop=crop, dtype="f16x2")
+    d = np.abs(img - g["image"])
+    print(f"\nf16x2 crop vs oracle: max {d.max():.2e} mean {d.mean():.2e} psnr {psnr(img, g['image']):.1f} dB")
+    _gate1(img, g["image"])
+    for kw in ({"skip_empty": True}, {"skip_dead": True}):
+        assert np.array_equal(native.render_image(renderer.coarse, renderer.fine, cam, 128, seed=0, crop=crop, dtype="f16x2", **kw), img)
+    cam40 = native.camera_from_samples(samples, 800, 800, 40)   # ragged chunks
+    a = native.render_image(renderer.coarse, renderer.fine, cam40, 50, seed=2, crop=(380, 360, 40, 24), dtype="f16x2", skip_dead=True)
+    assert np.array_equal(a, native.render_image(renderer.coarse, renderer.fine, cam40, 50, seed=2, crop=(380, 360, 40, 24), dtype="f16x2"))
+    g1 = golden("crop_c1_400_coarse_only.npz")                  # coarse-only: the coarse network itself in f16x2
+    cam4 = native.camera_from_samples(samples, 400, 400, 64)
+    c1 = native.render_image(renderer.coarse, renderer.fine, cam4, 0, seed=0, coarse_only=True, crop=tuple(int(v) for v in g1["crop"]), dtype="f16x2")
+    _gate1(c1, g1["image"])
+
+
+def test_f16x2_whole_frame(renderer, native, samples):
+    """BASELINE C3 at full size: Gate 1 against the oracle's whole frame, Gate 2, and skip_dead bit-identical with its timing."""
+    import json
+    frame = os.path.join(GOLDEN, "frame_c3_800_seed0.npz")
+    cam = native.camera_from_samples(samples, 800, 800, 64)
+    img, st = native.render_image(renderer.coarse, renderer.fine, cam, 128, seed=0, dtype="f16x2", return_stats=True)
+    dead, sd = native.render_image(renderer.coarse, renderer.fine, cam, 128, seed=0, dtype="f16x2", skip_dead=True, return_stats=True)
+    assert np.array_equal(dead, img)
+    print(f"\nf16x2 full frame: {st.n_rays / (st.ms_total * 1e-3):.0f} rays/s ({st.ms_total:.1f} ms: coarse {st.ms_coarse_mlp:.1f} fine {st.ms_fine_mlp:.1f}); "
+          f"with skip_dead {sd.n_rays / (sd.ms_total * 1e-3):.0f} rays/s ({sd.ms_total:.1f} ms: coarse {sd.ms_coarse_mlp:.1f} fine {sd.ms_fine_mlp:.1f})")
+    if os.path.exists(frame):
+        A = np.load(frame)
+        d = np.abs(img - A["image"])
+        q = native.quantize_rgb8(img)
+        step = np.abs(q.astype(np.int16) - A["rgb8"].astype(np.int16))
+        print(f"f16x2 whole frame vs oracle: max {d.max():.3e} mean {d.mean():.3e} psnr {psnr(img, A['image']):.2f} dB, rgb8 max step {step.max()}")
+        _gate1(img, A["image"])
+        assert step.max() <= 1 and (step == 0).mean() >= 0.9999
+        gates = json.load(open(os.path.join(GOLDEN, "frame_gates.json")))
+        s1 = native.render_image(renderer.coarse, renderer.fine, cam, 128, seed=1, dtype="f16x2")
+        assert abs(psnr(s1, A["image"]) - gates["cpu_seed1_vs_A"]) <= 0.1

@@ -288,6 +288,27 @@ def test_bf16x3_split_is_exact_to_2pow27_and_six_products_match_f32(native):
     assert (np.abs(six - exact) <= 2.0 ** -24 * np.abs(exact) + 1e-40).all()          # within half an f32 ulp of the true product
 
 
+def test_f16x2_split_is_exact_enough(native):
+    """The NERF_MLP_F16X2 packer's two-way f16 split: round to nearest even (numpy's float16 is the oracle), v = p0 + p1 to
+    2^-22 |v| (+ the f16 subnormal spacing), and the three products the kernel forms approximate the f32 product to 2^-21."""
+    rng = np.random.default_rng(5)
+    v = np.concatenate([rng.normal(size=20000) * 0.13, rng.uniform(-8.3, 8.3, 2000), rng.normal(size=2000) * 300.0,
+                        rng.normal(size=2000) * 1e-4, [0.0, 1.0, -1.0, 65504.0, 6.1e-5, 5.9e-8]]).astype(np.float32)
+    parts = np.empty((v.size, 2), np.uint16)
+    L = native.load_library()
+    assert L.nerf_debug_split_f16x2(v.ctypes.data_as(C.POINTER(C.c_float)), v.size, parts.ctypes.data_as(C.POINTER(C.c_uint16))) == 0
+    h = v.astype(np.float16)
+    l = (v - h.astype(np.float32)).astype(np.float16)
+    assert np.array_equal(parts[:, 0], h.view(np.uint16)) and np.array_equal(parts[:, 1], l.view(np.uint16))
+    p64 = parts.view(np.float16).astype(np.float64)
+    resid = np.abs(v.astype(np.float64) - p64.sum(axis=1))
+    assert (resid <= 2.0 ** -22 * np.abs(v) + 2.0 ** -25).all()
+    w, x = p64[:12000], p64[12000:24000]
+    three = (w[:, 1] * x[:, 0] + w[:, 0] * x[:, 1]) + w[:, 0] * x[:, 0]
+    exact = v[:12000].astype(np.float64) * v[12000:24000].astype(np.float64)
+    assert (np.abs(three - exact) <= 2.0 ** -21 * np.abs(exact) + 2.0 ** -24 * (np.abs(v[:12000]) + np.abs(v[12000:24000])) + 1e-12).all()
+
+
 def _c_prototypes(text):
     """name -> number of parameters, for every function declared in a C header (comments stripped)."""
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
