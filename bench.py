@@ -145,9 +145,9 @@ def main():
     ap.add_argument("--coarse", type=int, default=64)
     ap.add_argument("--fine", type=int, default=128)
     ap.add_argument("--seed", type=int, default=0)
-    ap.add_argument("--dtype", choices=["f32", "bf16", "bf16x3"], default="f32",
+    ap.add_argument("--dtype", choices=["f32", "bf16", "bf16x3", "f16x2"], default="f32",
                     help="MLP arithmetic: f32 = BASELINE's headline config (C3, default, f32 MFMA); bf16 = the C5 study (not the headline); "
-                         "bf16x3 = f32-accurate three-way bf16 split on the bf16 matrix cores (opt-in, meets the f32 tolerances)")
+                         "bf16x3 / f16x2 = f32-accurate operand splitting on the 16-bit matrix cores (opt-in, meet the f32 tolerances)")
     ap.add_argument("--ssaa", type=int, default=1, help="s x s rays per pixel (C5: --dtype bf16 --ssaa 2)")
     ap.add_argument("--skip-dead", action="store_true",
                     help="SURVEY 8f.2 (reported separately, not the headline): exact dead-sample skipping as the timed path (profiling runs); "
@@ -303,51 +303,51 @@ def main():
                               "weight > 0 export the trunk output (1 KiB) to a compacted buffer, a second launch runs bottleneck + viewdirs + "
                               "rgb on those only"}
         r.kernel_time_query(reset=True)
-    # Reported separately, never part of `value`: the same frame in the opt-in f32-accurate bf16x3 arithmetic.
-    extra_x3 = None
+    # Reported separately, never part of `value`: the same frame in the opt-in f32-accurate operand-splitting arithmetics
+    # (three bf16 parts, six products; DESIGN 4.7 f16x2: two f16 parts, three products), each also with
+    # exact dead-sample skipping on top.  The coarse (sampling) pass stays on the f32 MFMA kernel in both.
+    extra_split = {}
     if world == 1 and args.dtype == "f32" and not args.skip_empty and not args.skip_dead and not args.no_extra:
-        def x3_step():
-            N.render_image(r.coarse, r.fine, cam, args.fine, seed=args.seed, ssaa=args.ssaa, dtype="bf16x3",
-                           device_out=frame.data_ptr(), stream=stream)
+        n_r = args.width * args.height * args.ssaa * args.ssaa
         step(); torch.cuda.synchronize(dev)
-        ref_frame = frame.clone()
-        x3_step(); torch.cuda.synchronize(dev)
-        diff = (frame - ref_frame).abs()
-        x3_step(); torch.cuda.synchronize(dev)  # second warm frame: the clock settles at the power limit of the bf16 stream
-        t1 = time.perf_counter()
-        for _ in range(3):
-            x3_step()
-        torch.cuda.synchronize(dev)
-        ms = 1e3 * (time.perf_counter() - t1) / 3
-        extra_x3 = {"rays_per_s": args.width * args.height * args.ssaa * args.ssaa / (ms * 1e-3), "ms_per_step": ms,
-                    "max_abs_diff_vs_f32_frame": float(diff.max().item()), "mean_abs_diff_vs_f32_frame": float(diff.mean().item()),
-                    "fraction_of_values_differing_by_more_than_5e-5": float((diff > 5e-5).float().mean().item()),
-                    "psnr_vs_f32_frame_db": float(-10.0 * torch.log10((diff.double() ** 2).mean().clamp_min(1e-30)).item()),
-                    "note": "opt-in mlp_dtype bf16x3: the fine (colour) pass computes every f32 product as the six significant bf16 x bf16 "
-                            "products of three-way splits, f32 accumulate; the coarse (sampling) pass stays on the f32 MFMA kernel, so the "
-                            "fine sample positions equal the f32 path's bit for bit; passes the UNRELAXED Gate 1 against the oracle "
-                            "(tests/test_gpu_parity.py::test_bf16x3_render_matches_oracle_crop, tests/test_gpu_frame_fixture.py)"}
-        # ... and with exact dead-sample skipping on top of it (f32 ray-sequential coarse pass, bf16x3 trunk + colour kernels)
-        def x3d_step(stats=False):
-            return N.render_image(r.coarse, r.fine, cam, args.fine, seed=args.seed, ssaa=args.ssaa, dtype="bf16x3", skip_dead=True,
-                                  device_out=frame.data_ptr(), stream=stream, return_stats=stats)
-        x3_step(); torch.cuda.synchronize(dev)
-        x3_frame = frame.clone()
-        st = x3d_step(stats=True); torch.cuda.synchronize(dev)
-        identical = bool(torch.equal(frame, x3_frame))
-        x3d_step(); torch.cuda.synchronize(dev)
-        t1 = time.perf_counter()
-        for _ in range(3):
-            x3d_step()
-        torch.cuda.synchronize(dev)
-        ms = 1e3 * (time.perf_counter() - t1) / 3
-        extra_x3["with_skip_dead"] = {
-            "rays_per_s": args.width * args.height * args.ssaa * args.ssaa / (ms * 1e-3), "ms_per_step": ms,
-            "image_bit_identical_to_the_bf16x3_frame": identical,
-            "executed_fraction_coarse_trunk": st.n_exec_coarse_trunk / max(st.n_coarse_points, 1),
-            "executed_fraction_fine_trunk": st.n_exec_fine_trunk / max(st.n_fine_points, 1),
-            "executed_fraction_colour_head": st.n_exec_colour / max(st.n_fine_points, 1),
-            "device_ms": {"total": st.ms_total, "coarse_trunk_f32": st.ms_coarse_mlp, "fine_trunk_plus_colour_bf16x3": st.ms_fine_mlp, "other": st.ms_other}}
+        f32_frame = frame.clone()
+        notes = {"bf16x3": "opt-in mlp_dtype bf16x3: the fine (colour) pass computes every f32 product as the six significant bf16 x bf16 "
+                           "products of three-way splits, f32 accumulate; the coarse (sampling) pass stays on the f32 MFMA kernel, so the "
+                           "fine sample positions equal the f32 path's bit for bit; passes the UNRELAXED Gate 1 against the oracle "
+                           "(tests/test_gpu_parity.py::test_bf16x3_render_matches_oracle_crop, tests/test_gpu_frame_fixture.py)",
+                 "f16x2": "opt-in mlp_dtype f16x2: the fine (colour) pass computes every f32 product as the three significant f16 x f16 products "
+                          "of two-way splits (operands exact to 2^-22), f32 accumulate; f32 sampling pass as for bf16x3; passes the UNRELAXED "
+                          "Gate 1 against the oracle (tests/test_gpu_f16x2.py); f16 range: activations must stay below 65504"}
+        for dt in ("bf16x3", "f16x2"):
+            def split_step(dead=False, stats=False):
+                return N.render_image(r.coarse, r.fine, cam, args.fine, seed=args.seed, ssaa=args.ssaa, dtype=dt, skip_dead=dead,
+                                      device_out=frame.data_ptr(), stream=stream, return_stats=stats)
+
+            def timed(dead):
+                split_step(dead); split_step(dead); torch.cuda.synchronize(dev)  # warm frames: the clock settles at the power limit of the 16-bit MFMA stream
+                t1 = time.perf_counter()
+                for _ in range(3):
+                    split_step(dead)
+                torch.cuda.synchronize(dev)
+                return 1e3 * (time.perf_counter() - t1) / 3
+            ms = timed(False)
+            diff = (frame - f32_frame).abs()
+            split_frame = frame.clone()
+            e = {"rays_per_s": n_r / (ms * 1e-3), "ms_per_step": ms,
+                 "max_abs_diff_vs_f32_frame": float(diff.max().item()), "mean_abs_diff_vs_f32_frame": float(diff.mean().item()),
+                 "fraction_of_values_differing_by_more_than_5e-5": float((diff > 5e-5).float().mean().item()),
+                 "psnr_vs_f32_frame_db": float(-10.0 * torch.log10((diff.double() ** 2).mean().clamp_min(1e-30)).item()),
+                 "note": notes[dt]}
+            ms = timed(True)
+            identical = bool(torch.equal(frame, split_frame))
+            st = split_step(True, stats=True)
+            e["with_skip_dead"] = {
+                "rays_per_s": n_r / (ms * 1e-3), "ms_per_step": ms, f"image_bit_identical_to_the_{dt}_frame": identical,
+                "executed_fraction_coarse_trunk": st.n_exec_coarse_trunk / max(st.n_coarse_points, 1),
+                "executed_fraction_fine_trunk": st.n_exec_fine_trunk / max(st.n_fine_points, 1),
+                "executed_fraction_colour_head": st.n_exec_colour / max(st.n_fine_points, 1),
+                "device_ms": {"total": st.ms_total, "coarse_trunk_f32": st.ms_coarse_mlp, f"fine_trunk_plus_colour_{dt}": st.ms_fine_mlp, "other": st.ms_other}}
+            extra_split[dt] = e
         r.kernel_time_query(reset=True)
     # Reported separately, never part of `value`: BASELINE config C5's geometry on this one GPU -- 800x800 output, 2x2 SSAA
     # (1600x1600 = 2.56 M rays), bf16 operands / f32 accumulate (PSNR-level parity: tests/test_gpu_frame_fixture.py).
@@ -390,8 +390,11 @@ def main():
         flop_ray = N.flop_per_ray(args.coarse, args.fine)
         bf16 = args.dtype == "bf16"
         x3 = args.dtype == "bf16x3"
-        peak = PEAK_BF16_MFMA_TFLOPS if (bf16 or x3) else PEAK_FP32_MFMA_TFLOPS
-        mfma_per_flop = 6.0 if x3 else 1.0  # executed bf16 MFMA flops per algorithmic f32 flop
+        x2 = args.dtype == "f16x2"
+        split = x3 or x2
+        sfx = "x3" if x3 else "f16x2"  # kernel-name suffixes of the split arithmetics
+        peak = PEAK_BF16_MFMA_TFLOPS if (bf16 or split) else PEAK_FP32_MFMA_TFLOPS  # the f16 MFMA forms run at the bf16 rate
+        mfma_per_flop = 6.0 if x3 else 3.0 if x2 else 1.0  # executed 16-bit MFMA flops per algorithmic f32 flop
         value = n_rays * args.steps * (world if weak else 1) / dt  # whole-job rays/s over all ranks
         # executed flops of the dominant launches: a skipped sample still runs dense0..7 + alpha (sigma-only cost)
         flops_dom = pts_dom * N.FLOP_PER_POINT_FULL - n_dom * skipped_per_launch * (N.FLOP_PER_POINT_FULL - N.FLOP_PER_POINT_SIGMA)
@@ -399,10 +402,10 @@ def main():
             flops_dom = (n_dom / max(dead_stats.n_passes, 1)) * dead_stats.n_exec_fine_trunk * N.FLOP_PER_POINT_SIGMA  # one launch per pass
         ach = mfma_per_flop * flops_dom / (ms_dom * 1e-3) / 1e12 if ms_dom > 0 else 0.0
         traffic, traffic_src = pmc_traffic_bytes("void nerf_mlp_kernel_bf16v2<true" if bf16 else
-                                                 "void nerf_mlp_kernel_bf16x3<true" if x3 else
+                                                 "void nerf_mlp_kernel_bf16x3<true" if x3 else "void nerf_mlp_kernel_f16x2<true" if x2 else
                                                  "void nerf_trunk_seq_kernel<true" if args.skip_dead else "void nerf_mlp_kernel<true")
-        if args.skip_dead and x3:
-            traffic, traffic_src = pmc_traffic_bytes("void nerf_trunk_seq_kernel_x3<true")
+        if args.skip_dead and split:
+            traffic, traffic_src = pmc_traffic_bytes(f"void nerf_trunk_seq_kernel_{sfx}<true")
         line = {  # noqa: E501
             "metric": "rays/sec, lego 800x800 (64 coarse + 128 fine samples per ray)", "value": value, "unit": "rays/s",
             "n_gpus": world, "ranks": dist.get_world_size() if use_dist else 1,
@@ -412,10 +415,11 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
             "higher_is_better": True, "scaling": "weak" if weak else "strong", "vs_baseline": None,
             "dtype": ("bf16 operands / f32 accumulate (C5 study, PSNR-level parity)" if bf16 else
-                      "f32 as three-way bf16 split: 6 bf16 MFMA products per f32 product, f32 accumulate (f32-level parity)" if x3 else "f32"),
+                      "f32 as three-way bf16 split: 6 bf16 MFMA products per f32 product, f32 accumulate (f32-level parity)" if x3 else
+                      "f32 as two-way f16 split: 3 f16 MFMA products per f32 product, f32 accumulate (f32-level parity)" if x2 else "f32"),
             "data": "real lego weights (lego_rust/, 2 x 595,844 f32 parameters) + tf_reference_samples.json camera; "
                     "sample positions from the seeded counter RNG (no dataset involved)",
-            "config": {"workload": (f"C5-style: {args.ssaa}x{args.ssaa} SSAA, bf16 MLP, " if bf16 or args.ssaa > 1 else "C3 (bf16x3 arithmetic): " if x3 else "C3: ") +
+            "config": {"workload": (f"C5-style: {args.ssaa}x{args.ssaa} SSAA, bf16 MLP, " if bf16 or args.ssaa > 1 else f"C3 ({args.dtype} arithmetic): " if split else "C3: ") +
                                    f"lego coarse+fine hierarchical, {args.width}x{args.height}, {args.coarse}+{args.fine} "
                                    f"samples/ray, {args.dtype}, {world}xMI355X" +
                                    ("" if world == 1 else ", one frame per rank, no collective" if weak else ", row bands + RCCL all-gather"),
@@ -430,27 +434,27 @@ def main():
                          "frac": ach / peak, "traffic": traffic,
                          "traffic_source": (f"HBM bytes per launch from the committed rocprofv3 PMC passes ({traffic_src}; 2 x FETCH_SIZE + WRITE_SIZE "
                                             "in separate --pmc runs), not re-measured in this run; algorithmic: 20 B/point") if traffic_src else None,
-                         "kernel": (("nerf_trunk_seq_kernel_x3" if x3 else "nerf_trunk_seq_kernel") + "<EXPORT=true> (fine network, ray-sequential trunk; executed flops)"
+                         "kernel": ((f"nerf_trunk_seq_kernel_{sfx}" if split else "nerf_trunk_seq_kernel") + "<EXPORT=true> (fine network, ray-sequential trunk; executed flops)"
                                     if dead_stats is not None else
-                                    ("nerf_mlp_kernel_bf16v2" if bf16 else "nerf_mlp_kernel_bf16x3" if x3 else "nerf_mlp_kernel") +
+                                    ("nerf_mlp_kernel_bf16v2" if bf16 else "nerf_mlp_kernel_bf16x3" if x3 else "nerf_mlp_kernel_f16x2" if x2 else "nerf_mlp_kernel") +
                                     "<FULL=true, MODE_RAYS> (fine network)"),
                          "launches": n_dom, "avg_launch_ms": ms_dom / max(n_dom, 1),
                          "points_per_launch": pts_dom // max(n_dom, 1),
                          "flop_per_point": N.FLOP_PER_POINT_SIGMA if dead_stats is not None else N.FLOP_PER_POINT_FULL},
         }
-        if x3:
-            line["roofline"]["note"] = ("achieved/peak price the EXECUTED bf16 MFMA flops (6 per algorithmic f32 flop) against the bf16 peak; "
-                                        "f32_equivalent_tflops = algorithmic f32 flops / time")
-            line["roofline"]["f32_equivalent_tflops"] = ach / 6.0
-        if extra_x3:
-            line["extra_bf16x3"] = extra_x3
+        if split:
+            line["roofline"]["note"] = (f"achieved/peak price the EXECUTED 16-bit MFMA flops ({mfma_per_flop:.0f} per algorithmic f32 flop) against the "
+                                        "bf16/f16 peak; f32_equivalent_tflops = algorithmic f32 flops / time")
+            line["roofline"]["f32_equivalent_tflops"] = ach / mfma_per_flop
+        for dt, e in extra_split.items():
+            line["extra_" + dt] = e
         if extra_skip:
             line["extra_skip_empty"] = extra_skip
         if extra_dead:
             line["extra_skip_dead"] = extra_dead
         if extra_c5:
             line["extra_c5_bf16_ssaa2"] = extra_c5
-        if world == 1 and not args.no_cpu_baseline and not bf16 and not x3:
+        if world == 1 and not args.no_cpu_baseline and not bf16 and not split:
             line["cpu_baseline"] = cpu_baseline(args.width, args.height, args.coarse, args.fine, args.seed, not args.no_cpu_reference_order)
         print(json.dumps(line), flush=True)
     del out

@@ -172,34 +172,43 @@ __device__ __forceinline__ void prep_all(const f32x16 &in, B2 &b) {
 #define X2_PIN() __builtin_amdgcn_sched_barrier(0)
 
 // One k-step: NT units with the prepared B `bc`.  A unit = the three products of one 32 x 16 weight block, small terms first, on
-// one accumulator chain; the other work rides in its MFMA gaps: the next unit's two ds_reads and the LDS-DMA piece behind MFMA 1,
-// and behind MFMAs 1..3 the three stages of splitting one pair of the NEXT k-step's B operand (pair q in unit 2 q of an 8-tile
-// layer, unit q of viewdirs).
+// one accumulator chain; the other work rides in its three 32-cycle MFMA gaps, at most ~5 single-issue instructions each (the
+// guide's rule): the next unit's two ds_reads behind MFMA 1; the three stages of splitting one pair of the NEXT k-step's B operand
+// spread over a PAIR of units (8-tile layers: pair q in units 2q, 2q+1 -- stages 0, 1 behind MFMAs 2, 3 of the even unit, stage 2
+// behind MFMA 2 of the odd one; viewdirs, 4 units per k-step: all three stages in unit q); the LDS-DMA piece of units 4..7 behind
+// MFMA 1 (even units) or MFMA 3 (odd units, whose third gap is otherwise empty).
+#ifndef NERF_F16X2_SPREAD
+#define NERF_F16X2_SPREAD 1 // 0: everything behind MFMA 1 / per-unit stages (first version, 56.9 % of the bf16-class peak)
+#endif
 template <int NT, int U0, bool HAS_NEXT, bool NRELU, int NKS>
 __device__ __forceinline__ void k_step(f32x16 (&out)[8], const B2 &bc, const f32x16 &nin, B2 &bn, PipeH &P) {
     const f16x8 b1 = __builtin_bit_cast(f16x8, bc.h), b2 = __builtin_bit_cast(f16x8, bc.l);
+    PrepState st; // carried from the even to the odd unit of a pair
     static_for<0, NT>([&](auto nt_c) {
         constexpr int nt = decltype(nt_c)::value;
         constexpr int U = U0 + nt;
-        constexpr bool prep = HAS_NEXT && (NT == 4 || (nt & 1) == 0);
+        constexpr bool pairwise = NERF_F16X2_SPREAD && NT == 8;
+        constexpr bool even = (nt & 1) == 0;
         constexpr int Q = NT == 4 ? nt : nt / 2;
         f16x8 a1, a2;
-        PrepState st;
         pipe_take<U>(P, a1, a2);
         X2_PIN();
         out[nt] = MFMA16(a2, b1, out[nt]);
         X2_PIN();
         pipe_prefetch<U>(P);
-        pipe_dma<U>(P);
-        if constexpr (prep) prep_stage<NRELU, NKS, Q, 0>(nin, bn, st);
+        if constexpr (!pairwise || even) pipe_dma<U>(P);
+        if constexpr (HAS_NEXT && !pairwise && (NT == 4 || even)) prep_stage<NRELU, NKS, Q, 0>(nin, bn, st);
         X2_PIN();
         out[nt] = MFMA16(a1, b2, out[nt]);
         X2_PIN();
-        if constexpr (prep) prep_stage<NRELU, NKS, Q, 1>(nin, bn, st);
+        if constexpr (HAS_NEXT && pairwise) prep_stage<NRELU, NKS, Q, (even ? 0 : 2)>(nin, bn, st);
+        if constexpr (HAS_NEXT && !pairwise && (NT == 4 || even)) prep_stage<NRELU, NKS, Q, 1>(nin, bn, st);
         X2_PIN();
         out[nt] = MFMA16(a1, b1, out[nt]);
         X2_PIN();
-        if constexpr (prep) prep_stage<NRELU, NKS, Q, 2>(nin, bn, st);
+        if constexpr (HAS_NEXT && pairwise && even) prep_stage<NRELU, NKS, Q, 1>(nin, bn, st);
+        if constexpr (pairwise && !even) pipe_dma<U>(P);
+        if constexpr (HAS_NEXT && !pairwise && (NT == 4 || even)) prep_stage<NRELU, NKS, Q, 2>(nin, bn, st);
         X2_PIN();
     });
 }

@@ -16,7 +16,7 @@
 static void usage(const char *argv0) {
     fprintf(stderr,
             "usage: %s [--scene DIR] [--width W] [--height H] [--coarse N] [--fine N] [--seed S] [--ssaa S]\n"
-            "          [--coarse-only] [--crop X0,Y0,W,H] [--dtype f32|bf16|bf16x3] [--skip-empty] [--skip-dead]\n"
+            "          [--coarse-only] [--crop X0,Y0,W,H] [--dtype f32|bf16|bf16x3|f16x2] [--skip-empty] [--skip-dead]\n"
             "          [--device ID | --gpus N | --devices ID,ID,... [--gather host|peer|rccl]] [--frames K] [--out FILE.ppm]\n"
             "defaults: --scene lego_rust --width 256 --height 256 --coarse 64 --fine 128 --out output.ppm\n",
             argv0);
@@ -41,7 +41,7 @@ int main(int argc, char **argv) {
         else if (a == "--seed") opts.seed = strtoull(next(), nullptr, 10);
         else if (a == "--ssaa") opts.ssaa = atoi(next());
         else if (a == "--coarse-only") opts.coarse_only = 1;
-        else if (a == "--dtype") { const std::string d = next(); if (d == "bf16") opts.mlp_dtype = NERF_MLP_BF16; else if (d == "bf16x3") opts.mlp_dtype = NERF_MLP_BF16X3; else if (d != "f32") { usage(argv[0]); return 2; } }
+        else if (a == "--dtype") { const std::string d = next(); if (d == "bf16") opts.mlp_dtype = NERF_MLP_BF16; else if (d == "bf16x3") opts.mlp_dtype = NERF_MLP_BF16X3; else if (d == "f16x2") opts.mlp_dtype = NERF_MLP_F16X2; else if (d != "f32") { usage(argv[0]); return 2; } }
         else if (a == "--skip-empty") opts.skip_empty = 1;
         else if (a == "--skip-dead") opts.skip_dead = 1;
         else if (a == "--gpus") gpus = atoi(next());
@@ -106,7 +106,7 @@ int main(int argc, char **argv) {
     const double flop_ray = opts.coarse_only ? opts.n_coarse * 1186816.0
                                              : opts.n_coarse * 982528.0 + (double)(opts.n_coarse + opts.n_fine) * 1186816.0;
     const bool bf16 = opts.mlp_dtype != NERF_MLP_F32;
-    const double mfma_flops = opts.mlp_dtype == NERF_MLP_BF16X3 ? 6.0 : 1.0; // executed bf16 MFMA flops per algorithmic f32 flop
+    const double mfma_flops = opts.mlp_dtype == NERF_MLP_BF16X3 ? 6.0 : opts.mlp_dtype == NERF_MLP_F16X2 ? 3.0 : 1.0; // executed bf16 MFMA flops per algorithmic f32 flop
     if (gpus > 1) printf("%d GPUs, row bands gathered by %s\n", gpus, gather == NERF_GATHER_PEER ? "xGMI peer copies" : gather == NERF_GATHER_RCCL ? "one RCCL all-gather" : "direct D2H");
     printf("device %s (%d CUs): %.0f rays/s (best of %d, host wall incl. D2H); device %.1f ms = coarse MLP %.1f + fine MLP %.1f + other %.1f; "
            "%.1f%% of the %s MFMA roofline\n",

@@ -27,8 +27,8 @@ with N.Renderer(0) as r:
     mhz = C.c_double(0)
     if os.environ.get("NERF_DEBUG_CLOCK") and r._L.nerf_debug_shader_clock_mhz(r.handle, C.byref(mhz)) == 0:
         msg += f" clock {mhz.value:.0f} MHz"
-    peak = 2500.0 if dtype in ("bf16", "bf16x3") else 157.3
-    ex = 6.0 if dtype == "bf16x3" else 1.0  # executed bf16 MFMA flops per algorithmic f32 flop
+    peak = 2500.0 if dtype in ("bf16", "bf16x3", "f16x2") else 157.3
+    ex = 6.0 if dtype == "bf16x3" else 3.0 if dtype == "f16x2" else 1.0  # executed 16-bit MFMA flops per algorithmic f32 flop
     fl = ex * best.n_fine_points * 1186816 / (best.ms_fine_mlp * 1e-3) / 1e12
     cl = ex * best.n_coarse_points * 982528 / (best.ms_coarse_mlp * 1e-3) / 1e12
     print(f"{os.path.basename(N.lib_path()):34s} total {best.ms_total:8.2f} ms  coarse {best.ms_coarse_mlp:7.2f} ({cl:6.2f} TF)  "
