@@ -480,6 +480,9 @@ def test_odd_sample_counts_and_large_batches(renderer, native, oracle, oracle_ne
     _gate1(native.render_image(renderer.coarse, renderer.fine, cam, 50, seed=9, crop=crop, dtype="bf16x3"), ref)
     _gate1(native.render_image(renderer.coarse, renderer.fine, cam3, 5, seed=9, crop=crop, dtype="bf16x3"), ref3)
     _gate1(native.render_image(renderer.coarse, renderer.fine, cam2, 5, seed=9, crop=crop, dtype="bf16x3"), ref2)
+    _gate1(native.render_image(renderer.coarse, renderer.fine, cam, 50, seed=9, crop=crop, dtype="f16x2"), ref)
+    _gate1(native.render_image(renderer.coarse, renderer.fine, cam3, 5, seed=9, crop=crop, dtype="f16x2"), ref3)
+    _gate1(native.render_image(renderer.coarse, renderer.fine, cam2, 5, seed=9, crop=crop, dtype="f16x2"), ref2)
     assert psnr(native.render_image(renderer.coarse, renderer.fine, cam, 50, seed=9, crop=crop, dtype="bf16"), ref) >= 30.0
     assert psnr(native.render_image(renderer.coarse, renderer.fine, cam3, 5, seed=9, crop=crop, dtype="bf16"), ref3) >= 30.0
     # 3 M points through forward_batch: every 1000th point against the fixture values it repeats
@@ -571,7 +574,7 @@ def test_bf16x3_render_matches_oracle_crop(renderer, native, samples):
 def test_random_weight_network_all_arithmetics(native, oracle, tmp_path):
     """Nothing in the packers or kernels may depend on the lego weights: a network of the same architecture with random
     (He-scaled, dense, no zero rows) weights, written in the reference's directory format, must pass the same gates --
-    f32 and bf16x3 against the oracle at the f32 tolerances, bf16 against the oracle's bf16 emulation."""
+    f32, bf16x3 and f16x2 against the oracle at the f32 tolerances, bf16 against the oracle's bf16 emulation."""
     rng = np.random.default_rng(123)
     shapes = [("dense0", 63, 256)] + [(f"dense{i}", 256, 256) for i in range(1, 5)] + [("dense5", 319, 256), ("dense6", 256, 256),
               ("dense7", 256, 256), ("bottleneck", 256, 256), ("viewdirs", 283, 128), ("rgb", 128, 3), ("alpha", 256, 1)]
@@ -594,7 +597,7 @@ def test_random_weight_network_all_arithmetics(native, oracle, tmp_path):
     assert (esg > 0).mean() > 0.05 and np.isfinite(esg).all()           # a live network, not all-dead ReLUs
     with native.Renderer(0) as r:
         net = native.load_network_from_dir(r, 0, d)
-        for dt in ("f32", "bf16x3"):
+        for dt in ("f32", "bf16x3", "f16x2"):
             rgb, sg = net.forward_batch(pts, dirs, dtype=dt)
             _close_mlp(rgb, sg, ergb, esg)
         brgb, bsg = net.forward_batch(pts, dirs, dtype="bf16")
