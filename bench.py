@@ -241,6 +241,11 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     ms_dom, pts_dom, n_dom = r.kernel_time_query(reset=True)
+    # MAX over ranks of the timed region, taken right here (nothing below may touch it)
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev if not use_dist or dist.get_backend() == "nccl" else "cpu")
+    if use_dist:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
     skipped_per_launch = 0
     if args.skip_empty and world == 1:  # one extra untimed frame with stats: the skip count is deterministic per frame
         st = N.render_image(r.coarse, r.fine, cam, args.fine, seed=args.seed, ssaa=args.ssaa, dtype=args.dtype,
@@ -318,9 +323,9 @@ def main():
                  "f16x2": "opt-in mlp_dtype f16x2: the fine (colour) pass computes every f32 product as the three significant f16 x f16 products "
                           "of two-way splits (operands exact to 2^-22), f32 accumulate; f32 sampling pass as for bf16x3; passes the UNRELAXED "
                           "Gate 1 against the oracle (tests/test_gpu_f16x2.py); f16 range: activations must stay below 65504"}
-        for dt in ("bf16x3", "f16x2"):
+        for arith in ("bf16x3", "f16x2"):
             def split_step(dead=False, stats=False):
-                return N.render_image(r.coarse, r.fine, cam, args.fine, seed=args.seed, ssaa=args.ssaa, dtype=dt, skip_dead=dead,
+                return N.render_image(r.coarse, r.fine, cam, args.fine, seed=args.seed, ssaa=args.ssaa, dtype=arith, skip_dead=dead,
                                       device_out=frame.data_ptr(), stream=stream, return_stats=stats)
 
             def timed(dead):
@@ -337,17 +342,17 @@ def main():
                  "max_abs_diff_vs_f32_frame": float(diff.max().item()), "mean_abs_diff_vs_f32_frame": float(diff.mean().item()),
                  "fraction_of_values_differing_by_more_than_5e-5": float((diff > 5e-5).float().mean().item()),
                  "psnr_vs_f32_frame_db": float(-10.0 * torch.log10((diff.double() ** 2).mean().clamp_min(1e-30)).item()),
-                 "note": notes[dt]}
+                 "note": notes[arith]}
             ms = timed(True)
             identical = bool(torch.equal(frame, split_frame))
             st = split_step(True, stats=True)
             e["with_skip_dead"] = {
-                "rays_per_s": n_r / (ms * 1e-3), "ms_per_step": ms, f"image_bit_identical_to_the_{dt}_frame": identical,
+                "rays_per_s": n_r / (ms * 1e-3), "ms_per_step": ms, f"image_bit_identical_to_the_{arith}_frame": identical,
                 "executed_fraction_coarse_trunk": st.n_exec_coarse_trunk / max(st.n_coarse_points, 1),
                 "executed_fraction_fine_trunk": st.n_exec_fine_trunk / max(st.n_fine_points, 1),
                 "executed_fraction_colour_head": st.n_exec_colour / max(st.n_fine_points, 1),
-                "device_ms": {"total": st.ms_total, "coarse_trunk_f32": st.ms_coarse_mlp, f"fine_trunk_plus_colour_{dt}": st.ms_fine_mlp, "other": st.ms_other}}
-            extra_split[dt] = e
+                "device_ms": {"total": st.ms_total, "coarse_trunk_f32": st.ms_coarse_mlp, f"fine_trunk_plus_colour_{arith}": st.ms_fine_mlp, "other": st.ms_other}}
+            extra_split[arith] = e
         r.kernel_time_query(reset=True)
     # Reported separately, never part of `value`: BASELINE config C5's geometry on this one GPU -- 800x800 output, 2x2 SSAA
     # (1600x1600 = 2.56 M rays), bf16 operands / f32 accumulate (PSNR-level parity: tests/test_gpu_frame_fixture.py).
@@ -380,10 +385,6 @@ def main():
             host_frame.copy_(frame, non_blocking=True)
         torch.cuda.synchronize(dev)
         d2h_ms = 1e3 * (time.perf_counter() - t1) / 5
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev if not use_dist or dist.get_backend() == "nccl" else "cpu")
-    if use_dist:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax.item())
 
     if rank == 0:
         n_rays = args.width * args.height * args.ssaa * args.ssaa
@@ -446,8 +447,8 @@ def main():
             line["roofline"]["note"] = (f"achieved/peak price the EXECUTED 16-bit MFMA flops ({mfma_per_flop:.0f} per algorithmic f32 flop) against the "
                                         "bf16/f16 peak; f32_equivalent_tflops = algorithmic f32 flops / time")
             line["roofline"]["f32_equivalent_tflops"] = ach / mfma_per_flop
-        for dt, e in extra_split.items():
-            line["extra_" + dt] = e
+        for arith, e in extra_split.items():
+            line["extra_" + arith] = e
         if extra_skip:
             line["extra_skip_empty"] = extra_skip
         if extra_dead:

@@ -99,7 +99,7 @@ def test_skip_dead_argument_errors(renderer, native, samples):
     cam = native.camera_from_samples(samples, 64, 64, 64)
     with pytest.raises(native.NerfError) as e:
         native.render_image(renderer.coarse, renderer.fine, cam, 128, skip_dead=True, dtype="bf16")
-    assert e.value.code == -1 and "NERF_MLP_F32 and NERF_MLP_BF16X3 only" in e.value.msg
+    assert e.value.code == -1 and "NERF_MLP_F32, NERF_MLP_BF16X3 and NERF_MLP_F16X2 only" in e.value.msg
 
 
 def test_skip_dead_in_bf16x3_arithmetic(renderer, native, samples):
