@@ -38,6 +38,19 @@ constexpr int kCB = kChunkBytesF16X2, kRS = kRingSlotsF16X2;
 #define NERF_F16X2_AHEAD 2
 #endif
 constexpr int kAhead = NERF_F16X2_AHEAD; // operand prefetch distance in units (1..3); a unit is three MFMAs = 96 cycles
+// Timing-only diagnostics (results are WRONG with any of these set; never shipped): what the non-MFMA cycles are spent on
+#ifndef NERF_F16X2_DIAG_NO_BARRIER
+#define NERF_F16X2_DIAG_NO_BARRIER 0
+#endif
+#ifndef NERF_F16X2_DIAG_NO_DMA
+#define NERF_F16X2_DIAG_NO_DMA 0
+#endif
+#ifndef NERF_F16X2_DIAG_NO_PREP
+#define NERF_F16X2_DIAG_NO_PREP 0
+#endif
+#ifndef NERF_F16X2_DIAG_NO_LDS
+#define NERF_F16X2_DIAG_NO_LDS 0
+#endif
 
 template <int I, int N, class F>
 __device__ __forceinline__ void static_for(F &&f) {
@@ -106,7 +119,11 @@ __device__ __forceinline__ void pipe_start(PipeH &P) {
 template <int U>
 __device__ __forceinline__ void pipe_take(PipeH &P, f16x8 &a1, f16x8 &a2) {
     if constexpr (U == 4) {
+#if NERF_F16X2_DIAG_NO_BARRIER
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (kRS - 3)) : "memory");
+#else
         asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(4 * (kRS - 3)) : "memory");
+#endif
         pipe_next_chunk(P);
     }
     constexpr int cur = (U & 3) * 2;
@@ -123,14 +140,20 @@ __device__ __forceinline__ void pipe_prefetch(PipeH &P) {
         P.rd_base = P.ring_lane + off;
     }
     constexpr int nu = (U + kAhead) & 7;
+#if NERF_F16X2_DIAG_NO_LDS
+    (void)nu; // keep whatever the fragments hold
+#else
 #pragma unroll
     for (int s = 0; s < 2; ++s) P.a[nxt + s] = *(const LDS_AS u32x4 *)(P.rd_base + (2 * nu + s) * 1024);
+#endif
 }
 
 // the LDS-DMA piece issued behind unit U: the four pieces of the chunk selected at the last sync go out behind units 4..7
 template <int U>
 __device__ __forceinline__ void pipe_dma(PipeH &P) {
+#if !NERF_F16X2_DIAG_NO_DMA
     if constexpr (U >= 4) glds_piece_off<(U - 4) * 1024>(P.lane16, P.cur_src, P.cur_dst);
+#endif
 }
 
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
@@ -143,6 +166,10 @@ struct PrepState { f32x2 x; uint32_t h; };
 
 template <bool RELU, int KS, int Q, int STAGE>
 __device__ __forceinline__ void prep_stage(const f32x16 &in, B2 &b, PrepState &st) {
+#if NERF_F16X2_DIAG_NO_PREP
+    if constexpr (STAGE == 2) { b.h[Q] = 0x3c003c00u; b.l[Q] = 0u; }
+    return;
+#endif
     if constexpr (STAGE == 0) {
         float x0 = in[8 * KS + 2 * Q], x1 = in[8 * KS + 2 * Q + 1];
         asm volatile("" : "+v"(x0), "+v"(x1)); // keep the accumulator reads here (hipcc otherwise hoists a whole layer's)
