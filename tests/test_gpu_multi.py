@@ -3,10 +3,11 @@ framebuffer with no torch involved.  The test box has ONE MI355X, so the context
 split, the threads, the three gather paths' bookkeeping and the ragged cases; the result must be BIT-IDENTICAL to the
 single-context frame (per-pixel counter RNG).  The RCCL gather needs distinct devices (RCCL refuses two ranks on one GPU):
 it runs here at n = 1 and must refuse n = 2 on one device with a clear message."""
-import subprocess
-import sys
 import json
 import os
+import socket
+import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -118,7 +119,10 @@ def test_bench_rccl_paths_at_world_size_one():
     exchanged over gloo, then an RCCL sub-group for the data path."""
     for extra_env in ({}, {"NERF_BENCH_BACKEND": ""}):
         env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
-        env.update(NERF_BENCH_FORCE_DIST="1", MASTER_PORT="29517", **extra_env)
+        with socket.socket() as sk:                       # a free port for the one-rank rendezvous
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        env.update(NERF_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), **extra_env)
         p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "1", "--width", "96",
                             "--height", "80", "--no-extra", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, env=env)
         assert p.returncode == 0, p.stderr[-2000:]
