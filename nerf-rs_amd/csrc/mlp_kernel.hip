@@ -161,9 +161,10 @@ static hipError_t launch_t(const MlpArgs &a, int n_blocks, hipStream_t stream) {
 }
 
 hipError_t nerf_mlp_init() {
-    const void *ks[4] = {(const void *)nerf_mlp_kernel<true, MLP_MODE_POINTS>, (const void *)nerf_mlp_kernel<false, MLP_MODE_POINTS>,
-                         (const void *)nerf_mlp_kernel<true, MLP_MODE_RAYS>, (const void *)nerf_mlp_kernel<false, MLP_MODE_RAYS>};
-    for (int i = 0; i < 4; ++i) {
+    // forward_batch always evaluates the full head, so the sigma-only kernel exists in ray mode only
+    const void *ks[3] = {(const void *)nerf_mlp_kernel<true, MLP_MODE_POINTS>, (const void *)nerf_mlp_kernel<true, MLP_MODE_RAYS>,
+                         (const void *)nerf_mlp_kernel<false, MLP_MODE_RAYS>};
+    for (int i = 0; i < 3; ++i) {
         hipError_t e = hipFuncSetAttribute(ks[i], hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
         if (e != hipSuccess) return e;
     }
@@ -176,6 +177,6 @@ hipError_t nerf_mlp_launch(const MlpArgs &a, bool full, int n_blocks, hipStream_
     if (n_blocks > n_tiles) n_blocks = n_tiles;
     if (n_blocks < 1) n_blocks = 1;
     if (a.mode == MLP_MODE_POINTS)
-        return full ? launch_t<true, MLP_MODE_POINTS>(a, n_blocks, stream) : launch_t<false, MLP_MODE_POINTS>(a, n_blocks, stream);
+        return full ? launch_t<true, MLP_MODE_POINTS>(a, n_blocks, stream) : hipErrorInvalidValue; // no sigma-only forward_batch
     return full ? launch_t<true, MLP_MODE_RAYS>(a, n_blocks, stream) : launch_t<false, MLP_MODE_RAYS>(a, n_blocks, stream);
 }

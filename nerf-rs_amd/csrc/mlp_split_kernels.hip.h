@@ -248,9 +248,10 @@ static hipError_t launch_t(const MlpArgs &a, int n_blocks, hipStream_t stream) {
 }
 
 hipError_t SPLIT_FN_INIT() {
-    const void *ks[4] = {(const void *)SPLIT_KERNEL_FUSED<true, MLP_MODE_POINTS>, (const void *)SPLIT_KERNEL_FUSED<false, MLP_MODE_POINTS>,
-                         (const void *)SPLIT_KERNEL_FUSED<true, MLP_MODE_RAYS>, (const void *)SPLIT_KERNEL_FUSED<false, MLP_MODE_RAYS>};
-    for (int i = 0; i < 4; ++i) {
+    // forward_batch always evaluates the full head, so the sigma-only kernel exists in ray mode only
+    const void *ks[3] = {(const void *)SPLIT_KERNEL_FUSED<true, MLP_MODE_POINTS>, (const void *)SPLIT_KERNEL_FUSED<true, MLP_MODE_RAYS>,
+                         (const void *)SPLIT_KERNEL_FUSED<false, MLP_MODE_RAYS>};
+    for (int i = 0; i < 3; ++i) {
         hipError_t e = hipFuncSetAttribute(ks[i], hipFuncAttributeMaxDynamicSharedMemorySize, kSplitLdsBytes);
         if (e != hipSuccess) return e;
     }
@@ -263,6 +264,6 @@ hipError_t SPLIT_FN_LAUNCH(const MlpArgs &a, bool full, int n_blocks, hipStream_
     if (n_blocks > n_tiles) n_blocks = n_tiles;
     if (n_blocks < 1) n_blocks = 1;
     if (a.mode == MLP_MODE_POINTS)
-        return full ? launch_t<true, MLP_MODE_POINTS>(a, n_blocks, stream) : launch_t<false, MLP_MODE_POINTS>(a, n_blocks, stream);
+        return full ? launch_t<true, MLP_MODE_POINTS>(a, n_blocks, stream) : hipErrorInvalidValue; // no sigma-only forward_batch
     return full ? launch_t<true, MLP_MODE_RAYS>(a, n_blocks, stream) : launch_t<false, MLP_MODE_RAYS>(a, n_blocks, stream);
 }
