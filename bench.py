@@ -352,6 +352,27 @@ def main():
                 "executed_fraction_fine_trunk": st.n_exec_fine_trunk / max(st.n_fine_points, 1),
                 "executed_fraction_colour_head": st.n_exec_colour / max(st.n_fine_points, 1),
                 "device_ms": {"total": st.ms_total, "coarse_trunk_f32": st.ms_coarse_mlp, f"fine_trunk_plus_colour_{arith}": st.ms_fine_mlp, "other": st.ms_other}}
+            # ... and with the sampling pass in the split arithmetic too, ill-conditioned rays redone in f32
+            def hyb_step(stats=False):
+                return N.render_image(r.coarse, r.fine, cam, args.fine, seed=args.seed, ssaa=args.ssaa, dtype=arith, skip_dead=True,
+                                      hybrid_sampling=True, device_out=frame.data_ptr(), stream=stream, return_stats=stats)
+            hyb_step(); hyb_step(); torch.cuda.synchronize(dev)
+            t1 = time.perf_counter()
+            for _ in range(3):
+                hyb_step()
+            torch.cuda.synchronize(dev)
+            ms = 1e3 * (time.perf_counter() - t1) / 3
+            hd = (frame - split_frame).abs()
+            st = hyb_step(stats=True)
+            e["with_skip_dead_and_hybrid_sampling"] = {
+                "rays_per_s": n_r / (ms * 1e-3), "ms_per_step": ms,
+                f"max_abs_diff_vs_the_{arith}_frame": float(hd.max().item()), f"mean_abs_diff_vs_the_{arith}_frame": float(hd.mean().item()),
+                "fraction_of_rays_redone_in_f32": st.n_hybrid_rays / max(st.n_rays, 1),
+                "device_ms": {"total": st.ms_total, f"coarse_{arith}_plus_f32_redo": st.ms_coarse_mlp, f"fine_trunk_plus_colour_{arith}": st.ms_fine_mlp,
+                              "other": st.ms_other},
+                "note": "opt-in hybrid_sampling: coarse pass in the split arithmetic; rays with a hierarchical draw in a CDF bin lighter than 1e-2 "
+                        "are redone in exact f32 and resampled (bit-identical positions to the f32 sampling pass there, <= ~6e-6 in t elsewhere); "
+                        "Gate 1 against the oracle's whole frame: tests/test_gpu_f16x2.py::test_hybrid_sampling"}
             extra_split[arith] = e
         r.kernel_time_query(reset=True)
     # Reported separately, never part of `value`: BASELINE config C5's geometry on this one GPU -- 800x800 output, 2x2 SSAA

@@ -46,7 +46,7 @@ pub struct nerf_render_opts {
     pub mlp_dtype: i32,
     pub skip_empty: i32,
     pub skip_dead: i32,
-    pub reserved: [i32; 1],
+    pub hybrid_sampling: i32,
 }
 
 #[repr(C)]
@@ -65,6 +65,7 @@ pub struct nerf_stats {
     pub n_exec_coarse_trunk: u64,
     pub n_exec_fine_trunk: u64,
     pub n_exec_colour: u64,
+    pub n_hybrid_rays: u64,
 }
 
 /// `gather` of `nerf_render_image_multi`

@@ -87,7 +87,12 @@ typedef struct {
                            * on the samples whose weight is > 0 (compacted through HBM, second launch).  EXACT: the image is
                            * bit-identical to skip_dead = 0.  Takes precedence over skip_empty.  Default 0 so that timings are
                            * plain executed-FLOP figures; nerf_stats.n_exec_* report the evaluations actually executed. */
-    int32_t reserved[1];  /* must be 0 */
+    int32_t hybrid_sampling; /* ext (needs skip_dead = 1 and mlp_dtype BF16X3 or F16X2, hierarchical render): 1 = run the SAMPLING
+                           * (coarse) pass in the split arithmetic too, then redo in exact f32 only the rays that have a
+                           * hierarchical draw in a CDF bin lighter than 1e-2 -- the ill-conditioned positions, where a 1e-5
+                           * density difference moves a sample visibly.  Those rays get the f32 path's sample positions bit for
+                           * bit; the others move by <= ~6e-6 in t.  Not bit-identical to hybrid_sampling = 0 (pixels differ at
+                           * the 1e-6 level); held to the same Gate 1.  nerf_stats.n_hybrid_rays = rays redone in f32. */
 } nerf_render_opts;
 
 /* Device-side timing of the last render (HIP events on the render stream). */
@@ -104,6 +109,7 @@ typedef struct {
     uint64_t n_exec_coarse_trunk;  /* coarse network, dense0..7 + alpha */
     uint64_t n_exec_fine_trunk;    /* fine network, dense0..7 + alpha */
     uint64_t n_exec_colour;        /* bottleneck + viewdirs + rgb (fine network, or the coarse one when coarse_only) */
+    uint64_t n_hybrid_rays;        /* hybrid_sampling: rays whose coarse pass was redone in f32 (counted in n_exec_coarse_trunk too) */
 } nerf_stats;
 
 /* ---- lifecycle ------------------------------------------------------------------------------------------ */

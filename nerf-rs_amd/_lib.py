@@ -28,7 +28,7 @@ class CCamera(C.Structure):
 class COpts(C.Structure):
     _fields_ = [("n_coarse", C.c_int32), ("n_fine", C.c_int32), ("coarse_only", C.c_int32),
                 ("crop_x0", C.c_int32), ("crop_y0", C.c_int32), ("crop_w", C.c_int32), ("crop_h", C.c_int32),
-                ("ssaa", C.c_int32), ("seed", C.c_uint64), ("mlp_dtype", C.c_int32), ("skip_empty", C.c_int32), ("skip_dead", C.c_int32), ("reserved", C.c_int32 * 1)]
+                ("ssaa", C.c_int32), ("seed", C.c_uint64), ("mlp_dtype", C.c_int32), ("skip_empty", C.c_int32), ("skip_dead", C.c_int32), ("hybrid_sampling", C.c_int32)]
 
 
 class CStats(C.Structure):
@@ -36,7 +36,7 @@ class CStats(C.Structure):
                 ("ms_total", C.c_double), ("ms_coarse_mlp", C.c_double), ("ms_fine_mlp", C.c_double),
                 ("ms_other", C.c_double), ("n_mlp_launches", C.c_uint32), ("n_passes", C.c_uint32),
                 ("n_colour_skipped_points", C.c_uint64), ("n_exec_coarse_trunk", C.c_uint64), ("n_exec_fine_trunk", C.c_uint64),
-                ("n_exec_colour", C.c_uint64)]
+                ("n_exec_colour", C.c_uint64), ("n_hybrid_rays", C.c_uint64)]
 
 
 # name -> (restype, argtypes); kept in sync with include/nerf_mi355x.h (tests/test_abi.py checks the header)

@@ -55,6 +55,11 @@ struct SeqArgs {
     float *h8;
     unsigned int *slot_point;  // sample index (ray * samples_per_ray + k) of every exported slot
     unsigned long long *stats; // optional: += number of 32-sample chunks evaluated
+    // hybrid sampling: evaluate only the rays of a device-side list (n_rays then only bounds the grid); retired rays zero-fill the
+    // rest of their sigma row themselves (the row holds another arithmetic's values, the caller does not clear it)
+    const unsigned int *ray_list;
+    const unsigned int *ray_list_count;
+    int zero_fill_after_cut;
 };
 struct ColourArgs {
     const float *wstream;      // the same stream (bottleneck + viewdirs part is used)

@@ -38,7 +38,10 @@ __device__ __forceinline__ bool work_acquire(RayWork &W, const SeqArgs &A, LDS_A
         unsigned r = 0;
         if (lane == 0) r = atomicAdd(A.ray_counter, 1u);
         r = (unsigned)__builtin_amdgcn_readfirstlane((int)r);
-        W.ray = r < (unsigned)A.n_rays ? (int)r : A.n_rays;
+        if (A.ray_list) { // queue entries are positions in a device-side ray list (hybrid sampling)
+            const unsigned v = r < *A.ray_list_count ? A.ray_list[r] : (unsigned)A.n_rays;
+            W.ray = __builtin_amdgcn_readfirstlane((int)v);
+        } else W.ray = r < (unsigned)A.n_rays ? (int)r : A.n_rays;
         W.chunk = 0;
         W.T = 1.0f;
     }
@@ -121,6 +124,9 @@ __device__ __forceinline__ void chunk_finish(RayWork &W, const SeqArgs &A, const
             }
         }
     }
+    if (A.zero_fill_after_cut && cut && c.has && h == 0)
+        for (int cc = W.chunk + 1; cc < W.n_chunks; ++cc)
+            if (cc * 32 + p < M) A.sigma_out[c.base + cc * 32 + p] = 0.0f;
     W.chunk = (cut || !c.has) ? W.n_chunks : W.chunk + 1;
 }
 

@@ -252,21 +252,24 @@ int nerfint::render_device(nerf_ctx *c, const nerf_camera *cam, const nerf_rende
     if (!d_out) return fail(c, NERF_ERR_INVALID, "output pointer is NULL");
     if (o->n_coarse <= 0) return fail(c, NERF_ERR_INVALID, "coarse samples per ray must be greater than 0"); // src/lib.rs:483-486
     if (o->n_fine < 0) return fail(c, NERF_ERR_INVALID, "fine samples per ray must be >= 0");
-    for (int r : o->reserved) if (r != 0) return fail(c, NERF_ERR_INVALID, "reserved option fields must be 0");
     if (!valid_dtype(o->mlp_dtype)) return fail(c, NERF_ERR_INVALID, "mlp_dtype must be NERF_MLP_F32, NERF_MLP_BF16, NERF_MLP_BF16X3 or NERF_MLP_F16X2");
     const int dtype = o->mlp_dtype;
     // bf16x3 / f16x2: the sampling pass (coarse sigma -> CDF -> fine sample positions) stays on the exact-f32 MFMA kernel, so the fine
     // samples sit where the f32 path puts them bit for bit (a 1e-5 density difference can move a CDF entry across a fixed
     // uniform draw and relocate a sample -- a discontinuity, not an accuracy problem); only the colour-producing pass runs in
     // the three-way split arithmetic.
-    const int dtype_coarse = (split_dtype(dtype) && !o->coarse_only) ? NERF_MLP_F32 : dtype;
+    const int dtype_coarse = (split_dtype(dtype) && !o->coarse_only && !o->hybrid_sampling) ? NERF_MLP_F32 : dtype;
     if (o->skip_empty != 0 && o->skip_empty != 1) return fail(c, NERF_ERR_INVALID, "skip_empty must be 0 or 1");
     if (o->skip_dead != 0 && o->skip_dead != 1) return fail(c, NERF_ERR_INVALID, "skip_dead must be 0 or 1");
     if (o->skip_dead && dtype == NERF_MLP_BF16) return fail(c, NERF_ERR_INVALID, "skip_dead is implemented for NERF_MLP_F32, NERF_MLP_BF16X3 and NERF_MLP_F16X2 only");
     const bool seq = o->skip_dead != 0;
+    if (o->hybrid_sampling != 0 && o->hybrid_sampling != 1) return fail(c, NERF_ERR_INVALID, "hybrid_sampling must be 0 or 1");
+    if (o->hybrid_sampling && !(seq && split_dtype(dtype) && !o->coarse_only))
+        return fail(c, NERF_ERR_INVALID, "hybrid_sampling needs skip_dead = 1, mlp_dtype NERF_MLP_BF16X3 or NERF_MLP_F16X2, and a hierarchical render");
     if (!c->net[NERF_NET_COARSE].loaded) return fail(c, NERF_ERR_STATE, "coarse network not loaded");
     if (!o->coarse_only && !c->net[NERF_NET_FINE].loaded) return fail(c, NERF_ERR_STATE, "fine network not loaded");
-    if (dtype == NERF_MLP_F16X2 && !c->net[o->coarse_only ? NERF_NET_COARSE : NERF_NET_FINE].wstream_x2)
+    if (dtype == NERF_MLP_F16X2 && (!c->net[o->coarse_only ? NERF_NET_COARSE : NERF_NET_FINE].wstream_x2 ||
+                                    (o->hybrid_sampling && !c->net[NERF_NET_COARSE].wstream_x2)))
         return fail(c, NERF_ERR_STATE, "NERF_MLP_F16X2 is unavailable for this network: a weight exceeds the f16 range");
     const int s = o->ssaa > 1 ? o->ssaa : 1;
     int x0 = 0, y0 = 0, cw = cam->nx, ch = cam->ny;
@@ -278,6 +281,7 @@ int nerfint::render_device(nerf_ctx *c, const nerf_camera *cam, const nerf_rende
     // then runs on the coarse samples only
     const int nf = (o->coarse_only || o->n_fine == 0 || nc < 3) ? 0 : o->n_fine;
     const int M = nc + nf;
+    const bool hybrid = o->hybrid_sampling != 0 && nf > 0; // without resampling there is nothing to protect
     if (composite_lds_bytes(M) > 160 * 1024 || (nf > 0 && resample_lds_bytes(nc, nf) > 160 * 1024))
         return fail(c, NERF_ERR_INVALID, "too many samples per ray for the sampling / compositing kernels (one ray per wave in LDS)");
     const int RW = cw * s, RH = ch * s, RX0 = x0 * s, RY0 = y0 * s;
@@ -300,7 +304,7 @@ int nerfint::render_device(nerf_ctx *c, const nerf_camera *cam, const nerf_rende
     }
     const uint32_t n_passes_total = (uint32_t)((RH + rows_per_pass - 1) / rows_per_pass);
     if (seq) { // per MLP launch: {u32 ray queue head, u32 live-sample count, u64 evaluated 32-sample chunks}
-        const size_t slots = (size_t)n_passes_total * 2;
+        const size_t slots = (size_t)n_passes_total * 3; // per pass: coarse, fine, hybrid f32 redo of the coarse pass
         if (slots > c->seq_slots) {
             size_t bytes = c->seq_slots * 16;
             if ((rc = ensure_bytes(c, (void **)&c->d_seq, &bytes, slots * 16))) return rc;
@@ -310,6 +314,7 @@ int nerfint::render_device(nerf_ctx *c, const nerf_camera *cam, const nerf_rende
         const size_t pass_samples = rows_per_pass * RW * (size_t)M;
         if ((rc = ensure_bytes(c, (void **)&c->d_h8, &c->h8_bytes, nerf_seq_h8_bytes(pass_samples)))) return rc;
         if ((rc = ensure_bytes(c, (void **)&c->d_slot_point, &c->slot_point_bytes, (pass_samples + 128) * sizeof(unsigned int)))) return rc;
+        if (hybrid && (rc = ensure_bytes(c, (void **)&c->d_flag_list, &c->flag_list_bytes, rows_per_pass * RW * sizeof(unsigned int)))) return rc;
     }
     recycle_render(c);
     recycle_dominant(c, 4096); // bound the backlog if the caller never queries
@@ -373,7 +378,7 @@ int nerfint::render_device(nerf_ctx *c, const nerf_camera *cam, const nerf_rende
         a.sigma_out = c->d_sc; a.rgb_out = c->d_rgbc;
         a.skip_empty = o->skip_empty; a.skip_counter = o->skip_empty ? c->d_skip : nullptr; // only full kernels look at it
         if (seq) {
-            if ((rc = seq_pass(NC, dtype_coarse, nc, c->d_tc, c->d_sc, o->coarse_only ? c->d_rgbc : nullptr, 2 * (int)passes, o->coarse_only ? 1 : 0))) return rc;
+            if ((rc = seq_pass(NC, dtype_coarse, nc, c->d_tc, c->d_sc, o->coarse_only ? c->d_rgbc : nullptr, 3 * (int)passes, o->coarse_only ? 1 : 0))) return rc;
         } else {
             Timed t(c, st, o->coarse_only ? 1 : 0, (uint64_t)a.n_points, timing);
             HIP_TRY(c, launch_mlp(c, dtype_coarse, a, o->coarse_only != 0, st));
@@ -395,9 +400,34 @@ int nerfint::render_device(nerf_ctx *c, const nerf_camera *cam, const nerf_rende
             ra.g = g; ra.n_rays = n_rays; ra.nc = nc; ra.nf = nf; ra.far_ = cam->far_;
             ra.seed_lo = (uint32_t)o->seed; ra.seed_hi = (uint32_t)(o->seed >> 32);
             ra.t_coarse = c->d_tc; ra.sigma_coarse = c->d_sc; ra.t_fine = c->d_tf;
-            Timed t(c, st, 2, 0, timing);
-            HIP_TRY(c, launch_resample(ra, st));
-            t.done(c->last_render);
+            unsigned int *hctr = seq ? c->d_seq + 4 * (size_t)(3 * passes + 2) : nullptr; // {queue head, flagged-ray count, u64 chunks}
+            if (hybrid) { ra.flag_tau = c->hybrid_tau; ra.flag_count = hctr + 1; ra.flag_list = c->d_flag_list; }
+            {
+                Timed t(c, st, 2, 0, timing);
+                HIP_TRY(c, launch_resample(ra, st));
+                t.done(c->last_render);
+            }
+            if (hybrid) {
+                // The coarse densities came from the split arithmetic.  Redo, in exact f32, the rays with a draw in a light CDF
+                // bin (their sample positions are the ill-conditioned ones) and resample just those: same positions as the f32 path.
+                SeqArgs q{};
+                q.wstream = NC.wstream; q.small_params = NC.small; q.n_rays = n_rays; q.samples_per_ray = nc;
+                q.ray_dirs = c->d_dirs; q.t = c->d_tc; q.far_ = cam->far_;
+                q.origin[0] = cam->pos[0]; q.origin[1] = cam->pos[1]; q.origin[2] = cam->pos[2];
+                q.sigma_out = c->d_sc; q.ray_counter = hctr; q.live_count = hctr + 1; q.stats = (unsigned long long *)(hctr + 2);
+                q.ray_list = c->d_flag_list; q.ray_list_count = hctr + 1; q.zero_fill_after_cut = 1;
+                {
+                    Timed t(c, st, 0, 0, timing);
+                    HIP_TRY(c, nerf_trunk_seq_launch(q, false, c->n_cus, st));
+                    t.done(c->last_render);
+                }
+                ResampleArgs rb = ra;
+                rb.flag_tau = 0.0f; rb.flag_count = nullptr; rb.flag_list = nullptr;
+                rb.ray_list = c->d_flag_list; rb.ray_list_count = hctr + 1;
+                Timed t(c, st, 2, 0, timing);
+                HIP_TRY(c, launch_resample(rb, st));
+                t.done(c->last_render);
+            }
             t_fine = c->d_tf;
         }
         a.wstream = stream_of(NF, dtype); a.small_params = NF.small;
@@ -406,7 +436,7 @@ int nerfint::render_device(nerf_ctx *c, const nerf_camera *cam, const nerf_rende
         a.clock_out = c->d_clock; // NULL unless NERF_DEBUG_CLOCK=1
         c->clock_valid = c->d_clock != nullptr;
         if (seq) {
-            if ((rc = seq_pass(NF, dtype, M, t_fine, c->d_sf, c->d_rgbf, 2 * (int)passes + 1, 1))) return rc;
+            if ((rc = seq_pass(NF, dtype, M, t_fine, c->d_sf, c->d_rgbf, 3 * (int)passes + 1, 1))) return rc;
         } else {
             Timed t(c, st, 1, (uint64_t)a.n_points, timing);
             HIP_TRY(c, launch_mlp(c, dtype, a, true, st));
@@ -461,16 +491,17 @@ int nerfint::render_device(nerf_ctx *c, const nerf_camera *cam, const nerf_rende
         stats->n_exec_fine_trunk = stats->n_fine_points;
         stats->n_exec_colour = (o->coarse_only ? stats->n_coarse_points : stats->n_fine_points) - stats->n_colour_skipped_points;
         if (seq) {
-            std::vector<unsigned int> h((size_t)passes * 2 * 4);
+            std::vector<unsigned int> h((size_t)passes * 3 * 4);
             HIP_TRY(c, hipMemcpy(h.data(), c->d_seq, h.size() * sizeof(unsigned int), hipMemcpyDeviceToHost));
-            uint64_t chunks[2] = {0, 0}, live = 0;
-            for (uint32_t k = 0; k < passes * 2; ++k) {
+            uint64_t chunks[3] = {0, 0, 0}, live = 0;
+            for (uint32_t k = 0; k < passes * 3; ++k) {
                 unsigned long long ch64;
                 memcpy(&ch64, &h[4 * (size_t)k + 2], sizeof ch64);
-                chunks[k & 1] += ch64;
-                live += h[4 * (size_t)k + 1];
+                chunks[k % 3] += ch64;
+                if (k % 3 == 2) stats->n_hybrid_rays += h[4 * (size_t)k + 1]; // flagged rays redone in f32
+                else live += h[4 * (size_t)k + 1];
             }
-            stats->n_exec_coarse_trunk = chunks[0] * 32;
+            stats->n_exec_coarse_trunk = (chunks[0] + chunks[2]) * 32;
             stats->n_exec_fine_trunk = o->coarse_only ? 0 : chunks[1] * 32;
             stats->n_exec_colour = live;
             stats->n_colour_skipped_points = (o->coarse_only ? stats->n_coarse_points : stats->n_fine_points) - live;
@@ -526,6 +557,10 @@ int nerf_create(int device_id, nerf_ctx **out) try {
         const long long v = atoll(env);
         if (v > 0) c->max_export_bytes = (size_t)v;
     }
+    if (const char *env = getenv("NERF_HYBRID_TAU")) { // experiments only: the CDF-bin mass below which a ray is redone in f32
+        const double v = atof(env);
+        if (v >= 0.0 && v <= 1.0) c->hybrid_tau = (float)v;
+    }
     if (const char *env = getenv("NERF_DEBUG_CLOCK")) {
         if (atoi(env) > 0 && hipMalloc((void **)&c->d_clock, (size_t)c->n_cus * 2 * sizeof(unsigned long long)) != hipSuccess) c->d_clock = nullptr;
     }
@@ -571,6 +606,7 @@ void nerf_destroy(nerf_ctx *c) {
     if (c->d_seq) (void)hipFree(c->d_seq);
     if (c->d_h8) (void)hipFree(c->d_h8);
     if (c->d_slot_point) (void)hipFree(c->d_slot_point);
+    if (c->d_flag_list) (void)hipFree(c->d_flag_list);
     recycle_render(c);
     recycle_dominant(c, 0);
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);

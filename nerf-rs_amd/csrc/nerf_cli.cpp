@@ -16,7 +16,7 @@
 static void usage(const char *argv0) {
     fprintf(stderr,
             "usage: %s [--scene DIR] [--width W] [--height H] [--coarse N] [--fine N] [--seed S] [--ssaa S]\n"
-            "          [--coarse-only] [--crop X0,Y0,W,H] [--dtype f32|bf16|bf16x3|f16x2] [--skip-empty] [--skip-dead]\n"
+            "          [--coarse-only] [--crop X0,Y0,W,H] [--dtype f32|bf16|bf16x3|f16x2] [--skip-empty] [--skip-dead] [--hybrid-sampling]\n"
             "          [--device ID | --gpus N | --devices ID,ID,... [--gather host|peer|rccl]] [--frames K] [--out FILE.ppm]\n"
             "defaults: --scene lego_rust --width 256 --height 256 --coarse 64 --fine 128 --out output.ppm\n",
             argv0);
@@ -44,6 +44,7 @@ int main(int argc, char **argv) {
         else if (a == "--dtype") { const std::string d = next(); if (d == "bf16") opts.mlp_dtype = NERF_MLP_BF16; else if (d == "bf16x3") opts.mlp_dtype = NERF_MLP_BF16X3; else if (d == "f16x2") opts.mlp_dtype = NERF_MLP_F16X2; else if (d != "f32") { usage(argv[0]); return 2; } }
         else if (a == "--skip-empty") opts.skip_empty = 1;
         else if (a == "--skip-dead") opts.skip_dead = 1;
+        else if (a == "--hybrid-sampling") opts.hybrid_sampling = 1;
         else if (a == "--gpus") gpus = atoi(next());
         else if (a == "--devices") { // explicit device list, one context each (ids may repeat: several contexts on one GPU)
             devices.clear();

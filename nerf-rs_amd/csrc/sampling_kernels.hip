@@ -113,8 +113,12 @@ __device__ __forceinline__ float sample_alpha(const float *t, const float *sigma
 __global__ __launch_bounds__(256) void k_resample(ResampleArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds_f[];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int ray = blockIdx.x * 4 + wv;
+    int ray = blockIdx.x * 4 + wv;
     if (ray >= a.n_rays) return; // whole wave exits together; no block-level barrier below
+    if (a.ray_list) {            // second launch of the hybrid sampling pass: only the listed rays
+        if ((unsigned)ray >= *a.ray_list_count) return;
+        ray = (int)a.ray_list[ray];
+    }
     const int nc = a.nc, nf = a.nf, M = nc + nf;
     float *t = lds_f + (size_t)wv * (6 * nc + a.sort_pow2);
     float *sg = t + nc, *alpha = sg + nc, *w = alpha + nc, *cdf = w + nc, *bins = cdf + nc, *mg = bins + nc;
@@ -145,6 +149,7 @@ __global__ __launch_bounds__(256) void k_resample(ResampleArgs a) {
 
     const uint32_t pix = a.pixel_index ? a.pixel_index[ray]
                                        : (uint32_t)((a.g.ry0 + ray / a.g.rw) * a.g.rnx + (a.g.rx0 + ray % a.g.rw));
+    bool light = false; // some draw of this lane fell into a CDF bin lighter than flag_tau (ill-conditioned position)
     for (int s = lane; s < nf; s += 64) {
         float u;
         if (a.u_in) u = a.u_in[(size_t)ray * nf + s];
@@ -155,10 +160,15 @@ __global__ __launch_bounds__(256) void k_resample(ResampleArgs a) {
         while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (cdf[mid] <= u) lo = mid; else hi = mid - 1; }
         const float cl = cdf[lo], cu = cdf[lo + 1];
         float denom = cu - cl;
+        light = light || denom < a.flag_tau;
         if (!(denom > 1e-6f)) denom = 1e-6f;
         const float bl = bins[lo], bu = bins[lo + 1];
         const float tt = (u - cl) / denom;
         mg[nc + s] = bl + (bu - bl) * tt;
+    }
+    if (a.flag_list) { // wave-uniform branch; every lane votes
+        const bool any_light = __any(light);
+        if (any_light && lane == 0) a.flag_list[atomicAdd(a.flag_count, 1u)] = (unsigned)ray;
     }
     for (int i = lane; i < nc; i += 64) mg[i] = t[i];
     wave_sync();

@@ -117,3 +117,43 @@ def test_f16x2_whole_frame(renderer, native, samples):
         gates = json.load(open(os.path.join(GOLDEN, "frame_gates.json")))
         s1 = native.render_image(renderer.coarse, renderer.fine, cam, 128, seed=1, dtype="f16x2")
         assert abs(psnr(s1, A["image"]) - gates["cpu_seed1_vs_A"]) <= 0.1
+
+
+def test_hybrid_sampling(renderer, native, samples):
+    """hybrid_sampling: the coarse (sampling) pass runs in the split arithmetic too; rays with a hierarchical draw in a CDF bin
+    lighter than 1e-2 (the ill-conditioned sample positions) are redone in exact f32 and resampled.  Pixels then differ from the
+    f32-sampling frame only at the 1e-6 level, Gate 1 against the oracle holds, and a minority of the rays is redone."""
+    import json
+    cam = native.camera_from_samples(samples, 800, 800, 64)
+    g = golden("crop_c3_800_64_128.npz")
+    crop = tuple(int(v) for v in g["crop"])
+    for dt in ("f16x2", "bf16x3"):
+        base = native.render_image(renderer.coarse, renderer.fine, cam, 128, seed=0, crop=crop, dtype=dt, skip_dead=True)
+        hyb, st = native.render_image(renderer.coarse, renderer.fine, cam, 128, seed=0, crop=crop, dtype=dt, skip_dead=True,
+                                      hybrid_sampling=True, return_stats=True)
+        d = np.abs(hyb - base)
+        print(f"\n{dt} hybrid vs f32-sampling (crop, all foreground): max {d.max():.2e} mean {d.mean():.2e}; rays redone in f32 {st.n_hybrid_rays / st.n_rays:.3f}")
+        _gate1(hyb, g["image"])
+        assert d.max() <= 1e-4 and d.mean() <= 2e-6
+        assert 0 < st.n_hybrid_rays < 0.6 * st.n_rays
+        again = native.render_image(renderer.coarse, renderer.fine, cam, 128, seed=0, crop=crop, dtype=dt, skip_dead=True, hybrid_sampling=True)
+        assert np.array_equal(again, hyb)             # the flagged-ray list is built in arbitrary order; the result must not depend on it
+    # whole frame: Gate 1 against the oracle's whole frame, Gate 2, and what it buys
+    frame = os.path.join(GOLDEN, "frame_c3_800_seed0.npz")
+    img, st = native.render_image(renderer.coarse, renderer.fine, cam, 128, seed=0, dtype="f16x2", skip_dead=True, hybrid_sampling=True, return_stats=True)
+    print(f"f16x2 + skip_dead + hybrid_sampling full frame: {st.n_rays / (st.ms_total * 1e-3):.0f} rays/s ({st.ms_total:.1f} ms: coarse {st.ms_coarse_mlp:.1f} "
+          f"fine {st.ms_fine_mlp:.1f} other {st.ms_other:.1f}); rays redone in f32 {st.n_hybrid_rays / st.n_rays:.4f}")
+    assert st.n_hybrid_rays < 0.25 * st.n_rays
+    if os.path.exists(frame):
+        A = np.load(frame)
+        d = np.abs(img - A["image"])
+        print(f"hybrid whole frame vs oracle: max {d.max():.3e} mean {d.mean():.3e} psnr {psnr(img, A['image']):.2f} dB")
+        _gate1(img, A["image"])
+        gates = json.load(open(os.path.join(GOLDEN, "frame_gates.json")))
+        s1 = native.render_image(renderer.coarse, renderer.fine, cam, 128, seed=1, dtype="f16x2", skip_dead=True, hybrid_sampling=True)
+        assert abs(psnr(s1, A["image"]) - gates["cpu_seed1_vs_A"]) <= 0.1
+    # argument errors
+    for kw in ({"dtype": "f32", "skip_dead": True}, {"dtype": "f16x2"}, {"dtype": "f16x2", "skip_dead": True, "coarse_only": True}):
+        with pytest.raises(native.NerfError) as e:
+            native.render_image(renderer.coarse, renderer.fine, cam, 128, crop=(0, 0, 8, 8), hybrid_sampling=True, **kw)
+        assert e.value.code == -1 and "hybrid_sampling needs" in e.value.msg

@@ -351,7 +351,7 @@ def test_struct_sizes_match_the_library(native):
     L = native.load_library()
     a, b, c = C.c_size_t(), C.c_size_t(), C.c_size_t()
     L.nerf_abi_struct_sizes(C.byref(a), C.byref(b), C.byref(c))
-    assert (a.value, b.value, c.value) == (C.sizeof(_lib.CCamera), C.sizeof(_lib.COpts), C.sizeof(_lib.CStats)) == (60, 56, 96)
+    assert (a.value, b.value, c.value) == (C.sizeof(_lib.CCamera), C.sizeof(_lib.COpts), C.sizeof(_lib.CStats)) == (60, 56, 104)
 
 
 def test_loader_rejects_a_directory_named_like_a_tensor(native, tmp_path):
