@@ -370,8 +370,9 @@ def main():
                 "fraction_of_rays_redone_in_f32": st.n_hybrid_rays / max(st.n_rays, 1),
                 "device_ms": {"total": st.ms_total, f"coarse_{arith}_plus_f32_redo": st.ms_coarse_mlp, f"fine_trunk_plus_colour_{arith}": st.ms_fine_mlp,
                               "other": st.ms_other},
-                "note": "opt-in hybrid_sampling: coarse pass in the split arithmetic; rays with a hierarchical draw in a CDF bin lighter than 1e-2 "
-                        "are redone in exact f32 and resampled (bit-identical positions to the f32 sampling pass there, <= ~6e-6 in t elsewhere); "
+                "note": "opt-in hybrid_sampling: coarse pass in the split arithmetic; rays with a hierarchical draw predicted to move by more than 1e-5 in t "
+                        "(light CDF bins, nearly empty rays, transmittance near the cut) are redone in exact f32 and resampled (bit-identical "
+                        "positions to the f32 sampling pass there, <= 1e-5 in t elsewhere); "
                         "Gate 1 against the oracle's whole frame: tests/test_gpu_f16x2.py::test_hybrid_sampling"}
             extra_split[arith] = e
         r.kernel_time_query(reset=True)

@@ -557,7 +557,7 @@ int nerf_create(int device_id, nerf_ctx **out) try {
         const long long v = atoll(env);
         if (v > 0) c->max_export_bytes = (size_t)v;
     }
-    if (const char *env = getenv("NERF_HYBRID_TAU")) { // experiments only: the CDF-bin mass below which a ray is redone in f32
+    if (const char *env = getenv("NERF_HYBRID_TAU")) { // experiments only: the predicted sample displacement (in t) above which a ray is redone in f32
         const double v = atof(env);
         if (v >= 0.0 && v <= 1.0) c->hybrid_tau = (float)v;
     }

@@ -48,7 +48,7 @@ struct nerf_ctx {
     float *d_h8 = nullptr; size_t h8_bytes = 0;
     unsigned int *d_slot_point = nullptr; size_t slot_point_bytes = 0;
     unsigned int *d_flag_list = nullptr; size_t flag_list_bytes = 0; // hybrid sampling: rays whose coarse pass is redone in f32
-    float hybrid_tau = 1e-2f;                                        // a draw in a CDF bin lighter than this flags its ray
+    float hybrid_tau = 1e-5f;                                        // a draw predicted to move by more than this (in t) flags its ray
     size_t max_export_bytes = (size_t)48 << 30; // budget of d_h8: bounds the rays per pass in skip_dead mode (NERF_MAX_EXPORT_BYTES)
     unsigned long long *d_skip = nullptr;  // device counter of skipped 128-point tiles (skip_empty)
     unsigned long long *d_clock = nullptr; // diagnostic: per-workgroup {cycles, 100 MHz ticks} of the last fine-MLP launch

@@ -29,7 +29,8 @@ struct ResampleArgs {
     float *cdf_out;              // n_rays x (nc - 1)
     float *t_new_out;            // n_rays x nf (unsorted draws)
     int sort_pow2 = 0;           // set by launch_resample: smallest power of two >= nc + nf (bitonic sort width)
-    // hybrid sampling (nerf_render_opts.hybrid_sampling): flag the rays with a draw in a CDF bin lighter than flag_tau ...
+    // hybrid sampling (nerf_render_opts.hybrid_sampling): flag the rays with a draw whose position is predicted to move by more
+    // than flag_tau (in t) under the split arithmetics' density error ...
     float flag_tau = 0.0f;
     unsigned int *flag_count = nullptr; // device counter (zeroed by the caller)
     unsigned int *flag_list = nullptr;  // flagged ray indices, appended in arbitrary order

@@ -87,19 +87,23 @@ __global__ void k_stratified(RayGenArgs a, int count, float near_, float far_, u
 // ---- transmittance weights, shared by resample and composite ----------------------------------------
 // alpha[] in LDS -> w[] in LDS, sequential in sample order exactly as compute_weights (src/lib.rs:261-280).
 // Executed redundantly by every lane of the wave (wave-uniform control flow, LDS broadcast reads).
-__device__ __forceinline__ void weights_scan(const float *alpha, float *w, int n, int lane) {
+// Returns true if, before the cut, the transmittance passed within 0.1 % of the 1e-4 threshold: there a 1e-5 relative density
+// difference can flip the cut by one sample (hybrid sampling redoes such rays in f32; nobody else looks at the result).
+__device__ __forceinline__ bool weights_scan(const float *alpha, float *w, int n, int lane) {
     // branch-free form of the early break (src/lib.rs:273-279): once T < 1e-4 every later weight is 0 and T is not touched
     // again -- identical values, but the loop has no loop-carried branch, so the LDS reads pipeline
     float T = 1.0f;
-    bool cut = false;
+    bool cut = false, near = false;
 #pragma unroll 8
     for (int i = 0; i < n; ++i) {
         const float al = alpha[i];
         const float wi = cut ? 0.0f : T * al;
         if (lane == 0) w[i] = wi;
         T = cut ? T : T * (1.0f - al);
+        near = near || fabsf(T - 1e-4f) < 1e-7f;
         cut = cut || T < 1e-4f;
     }
+    return near;
 }
 
 __device__ __forceinline__ float sample_alpha(const float *t, const float *sigma, int i, int n, float far_) {
@@ -127,14 +131,20 @@ __global__ __launch_bounds__(256) void k_resample(ResampleArgs a) {
     wave_sync();
     for (int i = lane; i < nc; i += 64) alpha[i] = sample_alpha(t, sg, i, nc, a.far_);
     wave_sync();
-    weights_scan(alpha, w, nc, lane);
+    const bool near_cut = weights_scan(alpha, w, nc, lane);
     wave_sync();
     if (a.w_out) for (int i = lane; i < nc; i += 64) a.w_out[(size_t)ray * nc + i] = w[i];
 
     // sample_importance (src/lib.rs:289-351); nc >= 3 and nf > 0 guaranteed by the host
     const int m = nc - 2;
     for (int i = lane; i < nc - 1; i += 64) bins[i] = 0.5f * (t[i] + t[i + 1]);
-    for (int i = lane; i < m; i += 64) { const float x = w[i + 1]; alpha[i] = (x > 0.0f ? x : 0.0f) + 1e-5f; } // adjusted
+    int n_pos = 0; // interior samples that carry weight (wave-uniform; only hybrid sampling's error model looks at it)
+    for (int i = lane; i < m; i += 64) {
+        const float x = w[i + 1];
+        alpha[i] = (x > 0.0f ? x : 0.0f) + 1e-5f; // adjusted
+        n_pos += __popcll(__ballot(x > 0.0f));
+    }
+    n_pos = __builtin_amdgcn_readfirstlane(n_pos); // lanes that ran fewer iterations hold a partial count: lane 0 ran them all
     wave_sync();
     float sum = 0.0f;
     for (int i = 0; i < m; ++i) sum += alpha[i];                 // iter().sum(), sequential
@@ -149,7 +159,14 @@ __global__ __launch_bounds__(256) void k_resample(ResampleArgs a) {
 
     const uint32_t pix = a.pixel_index ? a.pixel_index[ray]
                                        : (uint32_t)((a.g.ry0 + ray / a.g.rw) * a.g.rnx + (a.g.rx0 + ray % a.g.rw));
-    bool light = false; // some draw of this lane fell into a CDF bin lighter than flag_tau (ill-conditioned position)
+    // Hybrid sampling: predicted |dCDF| of this ray if its densities carry the split arithmetics' error against the f32 kernel --
+    // an absolute part (1e-9 per sample that carries weight: |d sigma| ~ 1e-6 gives |dw| ~ 6e-8 over a ray's 62 bins; a sample with
+    // weight exactly 0 has no error) and a relative one (7e-7 of the weight sum), divided by the normalising sum (a nearly empty ray
+    // has a tiny sum: its CDF is the most sensitive), times a safety factor 3.  A draw whose position would move by more than
+    // flag_tau (|dt| = bin width x |dCDF| / bin mass) flags the ray.
+    const float sum_w = fmaxf(sum - (float)m * 1e-5f, 0.0f);
+    const float d_cdf = 3.0f * (1e-9f * (float)n_pos + 7e-7f * sum_w) / sum;
+    bool light = false;
     for (int s = lane; s < nf; s += 64) {
         float u;
         if (a.u_in) u = a.u_in[(size_t)ray * nf + s];
@@ -160,14 +177,14 @@ __global__ __launch_bounds__(256) void k_resample(ResampleArgs a) {
         while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (cdf[mid] <= u) lo = mid; else hi = mid - 1; }
         const float cl = cdf[lo], cu = cdf[lo + 1];
         float denom = cu - cl;
-        light = light || denom < a.flag_tau;
-        if (!(denom > 1e-6f)) denom = 1e-6f;
         const float bl = bins[lo], bu = bins[lo + 1];
+        light = light || !((bu - bl) * d_cdf <= a.flag_tau * denom);
+        if (!(denom > 1e-6f)) denom = 1e-6f;
         const float tt = (u - cl) / denom;
         mg[nc + s] = bl + (bu - bl) * tt;
     }
     if (a.flag_list) { // wave-uniform branch; every lane votes
-        const bool any_light = __any(light);
+        const bool any_light = __any(light) || near_cut; // an ill-conditioned draw, or a transmittance within 0.1 % of the cut
         if (any_light && lane == 0) a.flag_list[atomicAdd(a.flag_count, 1u)] = (unsigned)ray;
     }
     for (int i = lane; i < nc; i += 64) mg[i] = t[i];

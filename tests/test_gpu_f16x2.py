@@ -120,9 +120,10 @@ def test_f16x2_whole_frame(renderer, native, samples):
 
 
 def test_hybrid_sampling(renderer, native, samples):
-    """hybrid_sampling: the coarse (sampling) pass runs in the split arithmetic too; rays with a hierarchical draw in a CDF bin
-    lighter than 1e-2 (the ill-conditioned sample positions) are redone in exact f32 and resampled.  Pixels then differ from the
-    f32-sampling frame only at the 1e-6 level, Gate 1 against the oracle holds, and a minority of the rays is redone."""
+    """hybrid_sampling: the coarse (sampling) pass runs in the split arithmetic too; rays with a hierarchical draw whose position
+    is predicted to move by more than 1e-5 in t under that arithmetic's density error (light CDF bins, nearly empty rays, a
+    transmittance within 0.1 % of the cut) are redone in exact f32 and resampled.  Pixels then differ from the f32-sampling frame
+    at the 1e-8 level on average, Gate 1 against the oracle holds, and a minority of the rays is redone."""
     import json
     cam = native.camera_from_samples(samples, 800, 800, 64)
     g = golden("crop_c3_800_64_128.npz")
@@ -135,7 +136,7 @@ def test_hybrid_sampling(renderer, native, samples):
         print(f"\n{dt} hybrid vs f32-sampling (crop, all foreground): max {d.max():.2e} mean {d.mean():.2e}; rays redone in f32 {st.n_hybrid_rays / st.n_rays:.3f}")
         _gate1(hyb, g["image"])
         assert d.max() <= 1e-4 and d.mean() <= 2e-6
-        assert 0 < st.n_hybrid_rays < 0.6 * st.n_rays
+        assert 0 < st.n_hybrid_rays < 0.8 * st.n_rays          # this window is all foreground: the sensitive rays live here
         again = native.render_image(renderer.coarse, renderer.fine, cam, 128, seed=0, crop=crop, dtype=dt, skip_dead=True, hybrid_sampling=True)
         assert np.array_equal(again, hyb)             # the flagged-ray list is built in arbitrary order; the result must not depend on it
     # whole frame: Gate 1 against the oracle's whole frame, Gate 2, and what it buys
@@ -143,7 +144,7 @@ def test_hybrid_sampling(renderer, native, samples):
     img, st = native.render_image(renderer.coarse, renderer.fine, cam, 128, seed=0, dtype="f16x2", skip_dead=True, hybrid_sampling=True, return_stats=True)
     print(f"f16x2 + skip_dead + hybrid_sampling full frame: {st.n_rays / (st.ms_total * 1e-3):.0f} rays/s ({st.ms_total:.1f} ms: coarse {st.ms_coarse_mlp:.1f} "
           f"fine {st.ms_fine_mlp:.1f} other {st.ms_other:.1f}); rays redone in f32 {st.n_hybrid_rays / st.n_rays:.4f}")
-    assert st.n_hybrid_rays < 0.25 * st.n_rays
+    assert 0.05 * st.n_rays < st.n_hybrid_rays < 0.4 * st.n_rays
     if os.path.exists(frame):
         A = np.load(frame)
         d = np.abs(img - A["image"])
