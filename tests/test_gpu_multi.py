@@ -51,6 +51,16 @@ def test_multi_more_contexts_than_rows_and_golden_crop(native, samples, three):
     assert np.quantile(d, 0.999) <= 2e-5 and d.max() <= 2e-3
 
 
+def test_multi_with_skip_dead_and_hybrid_sampling(native, renderer, samples, three):
+    """The opt-in fast modes are per-ray decisions (ray queue, flagged-ray list), so banding must not change a bit of them."""
+    cam = native.camera_from_samples(samples, 800, 800, 64)
+    crop = (300, 330, 200, 47)
+    kw = dict(seed=0, crop=crop, dtype="f16x2", skip_dead=True, hybrid_sampling=True)
+    one = native.render_image(renderer.coarse, renderer.fine, cam, 128, **kw)
+    for n, gather in ((2, "host"), (3, "peer")):
+        assert np.array_equal(native.render_image_multi(three[:n], cam, 128, gather=gather, **kw), one)
+
+
 def test_multi_whole_frame_three_contexts(native, renderer, samples, three):
     cam = native.camera_from_samples(samples, 800, 800, 64)
     ref = native.render_image(renderer.coarse, renderer.fine, cam, 128, seed=0)
