@@ -152,6 +152,8 @@ def main():
     ap.add_argument("--skip-dead", action="store_true",
                     help="SURVEY 8f.2 (reported separately, not the headline): exact dead-sample skipping as the timed path (profiling runs); "
                          "the roofline line is then the ray-sequential trunk kernel priced in EXECUTED flops")
+    ap.add_argument("--hybrid-sampling", action="store_true",
+                    help="with --skip-dead and --dtype bf16x3|f16x2 (profiling runs): sampling pass in the split arithmetic, ill-conditioned rays redone in f32")
     ap.add_argument("--skip-empty", action="store_true",
                     help="SURVEY 8f.2 (reported separately, not the headline): skip the colour head of all-empty tiles; "
                          "the image is bit-identical, the roofline line then prices EXECUTED flops")
@@ -221,7 +223,8 @@ def main():
     def step():
         if not use_dist or weak:
             N.render_image(r.coarse, r.fine, cam, args.fine, seed=view_seed, ssaa=args.ssaa, dtype=args.dtype,
-                           skip_empty=args.skip_empty, skip_dead=args.skip_dead, device_out=frame.data_ptr(), stream=stream)
+                           skip_empty=args.skip_empty, skip_dead=args.skip_dead, hybrid_sampling=args.hybrid_sampling,
+                           device_out=frame.data_ptr(), stream=stream)
             return frame
         return N.render_image_distributed(r.coarse, r.fine, cam, args.fine, seed=args.seed, ssaa=args.ssaa, dtype=args.dtype,
                                           skip_empty=args.skip_empty, skip_dead=args.skip_dead, group=data_group, return_tensor=True)
@@ -255,7 +258,7 @@ def main():
     dead_stats = None
     if args.skip_dead and world == 1:  # one extra untimed frame with stats: the executed-work counts are deterministic per frame
         dead_stats = N.render_image(r.coarse, r.fine, cam, args.fine, seed=args.seed, ssaa=args.ssaa, dtype=args.dtype, skip_dead=True,
-                                    device_out=frame.data_ptr(), stream=stream, return_stats=True)
+                                    hybrid_sampling=args.hybrid_sampling, device_out=frame.data_ptr(), stream=stream, return_stats=True)
         r.kernel_time_query(reset=True)
     # Reported separately, never part of `value`: the same frame with exact empty-tile skipping.
     extra_skip = None
@@ -450,7 +453,7 @@ def main():
                        "frame": "left in HBM inside the timed region (value excludes PCIe)",
                        "d2h_ms_per_frame": d2h_ms,
                        "rays_per_s_including_d2h": (n_rays / (dt / args.steps + 1e-3 * d2h_ms)) if d2h_ms is not None else None,
-                       "skip_empty": bool(args.skip_empty), "skip_dead": bool(args.skip_dead),
+                       "skip_empty": bool(args.skip_empty), "skip_dead": bool(args.skip_dead), "hybrid_sampling": bool(args.hybrid_sampling),
                        "colour_head_skipped_samples_per_frame": skipped_per_launch,
                        "whole_job_fraction_of_mfma_roofline": mfma_per_flop * value * flop_ray / (world * peak * 1e12)},  # per-GPU average
             "roofline": {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
