@@ -166,77 +166,6 @@ __device__ __forceinline__ void k_step(f32x16 (&out)[8], const B3 &bc, const f32
     });
 }
 
-// One input tile (two k-steps) of a layer with NT output tiles.  `b` holds the split B of this tile's k-step 0 on entry and
-// of the next tile's k-step 0 on exit (if HAS_NEXT).  Every tile starts on a chunk boundary: a k-step is 8 units = one chunk in
-// the 8-tile layers and 4 units in the 4-tile viewdirs layer, where the tile's second k-step therefore starts at unit 4.
-template <int NT, bool RELU, bool ACC_IN, bool HAS_NEXT, bool NRELU, bool NACC_IN>
-__device__ __forceinline__ void tile_steps(f32x16 &in, f32x16 &nin, f32x16 (&out)[8], B3 &b, PipeX &P) {
-    if constexpr (ACC_IN) asm volatile("" : "+a"(in));
-    B3 b1;
-    k_step<NT, 0, true, RELU, 1>(out, b, in, b1, P);
-    if constexpr (HAS_NEXT && NACC_IN) asm volatile("" : "+a"(nin));
-    k_step<NT, (NT == 8 ? 0 : 4), HAS_NEXT, NRELU, 0>(out, b1, nin, b, P);
-    // keep every accumulation chain in program order (see mlp_kernel_bf16.hip)
-    if constexpr (NT == 8)
-        asm volatile("" : "+a"(out[0]), "+a"(out[1]), "+a"(out[2]), "+a"(out[3]), "+a"(out[4]), "+a"(out[5]), "+a"(out[6]), "+a"(out[7]));
-    else
-        asm volatile("" : "+a"(out[0]), "+a"(out[1]), "+a"(out[2]), "+a"(out[3]));
-}
-
-template <int NT>
-__device__ __forceinline__ void load_bias(f32x16 (&out)[8], const LDS_AS float *bias, int h) {
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-        const LDS_AS f32x4 *b = (const LDS_AS f32x4 *)(bias + (nt * 2 + h) * 16);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const f32x4 v = b[q];
-            out[nt][4 * q + 0] = v[0]; out[nt][4 * q + 1] = v[1]; out[nt][4 * q + 2] = v[2]; out[nt][4 * q + 3] = v[3];
-        }
-    }
-}
-
-// the 8 input tiles of a 256-wide activation; `b` = split B of in[0]'s k-step 0 on entry
-template <int NT, bool RELU>
-__device__ __forceinline__ void eight_tiles(f32x16 (&in)[8], f32x16 (&out)[8], B3 &b, PipeX &P) {
-    tile_steps<NT, RELU, true, true, RELU, true>(in[0], in[1], out, b, P);
-    tile_steps<NT, RELU, true, true, RELU, true>(in[1], in[2], out, b, P);
-    tile_steps<NT, RELU, true, true, RELU, true>(in[2], in[3], out, b, P);
-    tile_steps<NT, RELU, true, true, RELU, true>(in[3], in[4], out, b, P);
-    tile_steps<NT, RELU, true, true, RELU, true>(in[4], in[5], out, b, P);
-    tile_steps<NT, RELU, true, true, RELU, true>(in[5], in[6], out, b, P);
-    tile_steps<NT, RELU, true, true, RELU, true>(in[6], in[7], out, b, P);
-}
-
-template <bool RELU>
-__device__ __forceinline__ void hidden_layer(f32x16 (&in)[8], f32x16 (&out)[8], const LDS_AS float *bias, PipeX &P, int h) {
-    load_bias<8>(out, bias, h);
-    B3 b;
-    asm volatile("" : "+a"(in[0]));
-    prep_all<RELU, 0>(in[0], b);
-    eight_tiles<8, RELU>(in, out, b, P);
-    tile_steps<8, RELU, true, false, false, false>(in[7], in[7], out, b, P);
-}
-
-__device__ __forceinline__ float alpha_head(const f32x16 (&Y)[8], const LDS_AS float *small, int h) {
-    const LDS_AS f32x4 *w = (const LDS_AS f32x4 *)(small + kAlphaWOff + h * 128);
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-#pragma unroll
-    for (int t = 0; t < 8; ++t) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            float x0 = Y[t][4 * q + 0], x1 = Y[t][4 * q + 1], x2 = Y[t][4 * q + 2], x3 = Y[t][4 * q + 3];
-            asm volatile("" : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3));
-            const f32x4 wv = w[t * 4 + q];
-            a0 = fmaf(wv[0], relu(x0), a0);
-            a1 = fmaf(wv[1], relu(x1), a1);
-            a2 = fmaf(wv[2], relu(x2), a2);
-            a3 = fmaf(wv[3], relu(x3), a3);
-        }
-    }
-    return fmaxf(xhalf_sum((a0 + a1) + (a2 + a3)) + small[kMiscOff + 0], 0.f);
-}
-
 using PipeS = PipeX;
 using BS = B3;
 constexpr int kSplitChunksSigma = kChunksSigmaX3, kSplitChunksFull = kChunksFullX3, kSplitLdsBytes = kLdsBytesX3;

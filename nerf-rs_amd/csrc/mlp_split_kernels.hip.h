@@ -1,14 +1,91 @@
 // mlp_split_kernels.hip.h -- the kernel bodies shared by the "f32 by operand splitting" arithmetics: bf16x3
 // (mlp_kernel_bf16x3.hip: three bf16 parts, six products) and f16x2 (mlp_kernel_f16x2.hip: two f16 parts, three products).
 // Textually included at the end of each of those files, after the file has defined, in an anonymous namespace, its
-// primitives -- PipeS (weight-stream pipeline) with pipe_start(), BS (split B operand), prep_all, tile_steps, eight_tiles,
-// hidden_layer, load_bias, alpha_head, kCB / kRS, kSplitChunksSigma / kSplitChunksFull, kSplitLdsBytes, kSplitWaveBytes --
+// primitives -- PipeS (weight-stream pipeline) with pipe_start(), BS (split B operand), prep_all, k_step, kCB / kRS,
+// kSplitChunksSigma / kSplitChunksFull, kSplitLdsBytes, kSplitWaveBytes (the layers built from them -- tile_steps, eight_tiles,
+// hidden_layer, load_bias, alpha_head -- are defined here, once) --
 // and the SPLIT_* names of the kernels and host functions it instantiates here:
 //   SPLIT_KERNEL_FUSED<FULL, MODE>   the fused MLP (forward_batch + point fill), structure of mlp_kernel.hip
 //   SPLIT_KERNEL_TRUNK<EXPORT>       skip_dead: ray-sequential trunk     } scheme: mlp_kernel_seq.hip,
 //   SPLIT_KERNEL_COLOUR              skip_dead: compacted colour head    } shared half: mlp_seq_common.hip.h
 // The accumulator tiles have the f32 kernel's register layout (C/D of the 32x32 MFMAs), so the small parameters and the
 // exported h8 tiles are shared with it.
+
+// ---- layers on top of the arithmetic's k_step / prep_all (identical for every split arithmetic) ---------------------------------
+namespace {
+
+// One input tile (two k-steps) of a layer with NT output tiles.  `b` holds the split B of this tile's k-step 0 on entry and
+// of the next tile's k-step 0 on exit (if HAS_NEXT).  Every tile starts on a chunk boundary: a k-step is 8 units = one chunk in
+// the 8-tile layers and 4 units in the 4-tile viewdirs layer, where the tile's second k-step therefore starts at unit 4.
+template <int NT, bool RELU, bool ACC_IN, bool HAS_NEXT, bool NRELU, bool NACC_IN>
+__device__ __forceinline__ void tile_steps(f32x16 &in, f32x16 &nin, f32x16 (&out)[8], BS &b, PipeS &P) {
+    if constexpr (ACC_IN) asm volatile("" : "+a"(in));
+    BS b1;
+    k_step<NT, 0, true, RELU, 1>(out, b, in, b1, P);
+    if constexpr (HAS_NEXT && NACC_IN) asm volatile("" : "+a"(nin));
+    k_step<NT, (NT == 8 ? 0 : 4), HAS_NEXT, NRELU, 0>(out, b1, nin, b, P);
+    // keep every accumulation chain in program order (hipcc otherwise defers whole chains across the sched_barriers)
+    if constexpr (NT == 8)
+        asm volatile("" : "+a"(out[0]), "+a"(out[1]), "+a"(out[2]), "+a"(out[3]), "+a"(out[4]), "+a"(out[5]), "+a"(out[6]), "+a"(out[7]));
+    else
+        asm volatile("" : "+a"(out[0]), "+a"(out[1]), "+a"(out[2]), "+a"(out[3]));
+}
+
+template <int NT>
+__device__ __forceinline__ void load_bias(f32x16 (&out)[8], const LDS_AS float *bias, int h) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const LDS_AS f32x4 *b = (const LDS_AS f32x4 *)(bias + (nt * 2 + h) * 16);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 v = b[q];
+            out[nt][4 * q + 0] = v[0]; out[nt][4 * q + 1] = v[1]; out[nt][4 * q + 2] = v[2]; out[nt][4 * q + 3] = v[3];
+        }
+    }
+}
+
+// the 8 input tiles of a 256-wide activation; `b` = split B of in[0]'s k-step 0 on entry
+template <int NT, bool RELU>
+__device__ __forceinline__ void eight_tiles(f32x16 (&in)[8], f32x16 (&out)[8], BS &b, PipeS &P) {
+    tile_steps<NT, RELU, true, true, RELU, true>(in[0], in[1], out, b, P);
+    tile_steps<NT, RELU, true, true, RELU, true>(in[1], in[2], out, b, P);
+    tile_steps<NT, RELU, true, true, RELU, true>(in[2], in[3], out, b, P);
+    tile_steps<NT, RELU, true, true, RELU, true>(in[3], in[4], out, b, P);
+    tile_steps<NT, RELU, true, true, RELU, true>(in[4], in[5], out, b, P);
+    tile_steps<NT, RELU, true, true, RELU, true>(in[5], in[6], out, b, P);
+    tile_steps<NT, RELU, true, true, RELU, true>(in[6], in[7], out, b, P);
+}
+
+template <bool RELU>
+__device__ __forceinline__ void hidden_layer(f32x16 (&in)[8], f32x16 (&out)[8], const LDS_AS float *bias, PipeS &P, int h) {
+    load_bias<8>(out, bias, h);
+    BS b;
+    asm volatile("" : "+a"(in[0]));
+    prep_all<RELU, 0>(in[0], b);
+    eight_tiles<8, RELU>(in, out, b, P);
+    tile_steps<8, RELU, true, false, false, false>(in[7], in[7], out, b, P);
+}
+
+__device__ __forceinline__ float alpha_head(const f32x16 (&Y)[8], const LDS_AS float *small, int h) {
+    const LDS_AS f32x4 *w = (const LDS_AS f32x4 *)(small + kAlphaWOff + h * 128);
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float x0 = Y[t][4 * q + 0], x1 = Y[t][4 * q + 1], x2 = Y[t][4 * q + 2], x3 = Y[t][4 * q + 3];
+            asm volatile("" : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3));
+            const f32x4 wv = w[t * 4 + q];
+            a0 = fmaf(wv[0], relu(x0), a0);
+            a1 = fmaf(wv[1], relu(x1), a1);
+            a2 = fmaf(wv[2], relu(x2), a2);
+            a3 = fmaf(wv[3], relu(x3), a3);
+        }
+    }
+    return fmaxf(xhalf_sum((a0 + a1) + (a2 + a3)) + small[kMiscOff + 0], 0.f);
+}
+
+} // namespace
 
 template <bool FULL, int MODE>
 __global__ __launch_bounds__(256, 1) void SPLIT_KERNEL_FUSED(const MlpArgs A) {
