@@ -310,6 +310,22 @@ def main():
                               "device-side ray queue and retires it at the reference's T < 1e-4 cut (src/lib.rs:276-279); samples with "
                               "weight > 0 export the trunk output (1 KiB) to a compacted buffer, a second launch runs bottleneck + viewdirs + "
                               "rgb on those only"}
+        # ... and with hybrid sampling on top: f16x2 sampling pass, ill-conditioned rays redone in f32, exact-f32 fine pass
+        def dead_hyb_step(stats=False):
+            return N.render_image(r.coarse, r.fine, cam, args.fine, seed=args.seed, ssaa=args.ssaa, skip_dead=True, hybrid_sampling=True,
+                                  device_out=frame.data_ptr(), stream=stream, return_stats=stats)
+        dead_hyb_step(); torch.cuda.synchronize(dev)
+        hd = (frame - ref_frame).abs()
+        t1 = time.perf_counter()
+        for _ in range(3):
+            dead_hyb_step()
+        torch.cuda.synchronize(dev)
+        ms = 1e3 * (time.perf_counter() - t1) / 3
+        st = dead_hyb_step(stats=True)
+        extra_dead["with_hybrid_sampling"] = {
+            "rays_per_s": n_r / (ms * 1e-3), "ms_per_step": ms, "max_abs_diff_vs_headline_frame": float(hd.max().item()),
+            "mean_abs_diff_vs_headline_frame": float(hd.mean().item()), "fraction_of_rays_redone_in_f32": st.n_hybrid_rays / max(st.n_rays, 1),
+            "device_ms": {"total": st.ms_total, "coarse_f16x2_plus_f32_redo": st.ms_coarse_mlp, "fine_trunk_plus_colour_f32": st.ms_fine_mlp, "other": st.ms_other}}
         r.kernel_time_query(reset=True)
     # Reported separately, never part of `value`: the same frame in the opt-in f32-accurate operand-splitting arithmetics
     # (three bf16 parts, six products; DESIGN 4.7 f16x2: two f16 parts, three products), each also with

@@ -87,8 +87,9 @@ typedef struct {
                            * on the samples whose weight is > 0 (compacted through HBM, second launch).  EXACT: the image is
                            * bit-identical to skip_dead = 0.  Takes precedence over skip_empty.  Default 0 so that timings are
                            * plain executed-FLOP figures; nerf_stats.n_exec_* report the evaluations actually executed. */
-    int32_t hybrid_sampling; /* ext (needs skip_dead = 1 and mlp_dtype BF16X3 or F16X2, hierarchical render): 1 = run the SAMPLING
-                           * (coarse) pass in the split arithmetic too, then redo in exact f32 only the rays with an ill-conditioned
+    int32_t hybrid_sampling; /* ext (needs skip_dead = 1, hierarchical render): 1 = run the SAMPLING (coarse) pass in a split
+                           * arithmetic (the render's own; for an F32 render f16x2, or bf16x3 if the network exceeds the f16 range;
+                           * the fine pass keeps mlp_dtype), then redo in exact f32 only the rays with an ill-conditioned
                            * hierarchical draw: one whose position is predicted to move by more than 1e-5 in t under the split
                            * arithmetic's density error (|dt| = bin width x |dCDF| / bin mass: light CDF bins, nearly empty rays),
                            * or whose transmittance passes within 0.1 % of the 1e-4 cut.  Those rays (27 % of the lego frame) get

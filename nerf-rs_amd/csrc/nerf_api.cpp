@@ -258,14 +258,17 @@ int nerfint::render_device(nerf_ctx *c, const nerf_camera *cam, const nerf_rende
     // samples sit where the f32 path puts them bit for bit (a 1e-5 density difference can move a CDF entry across a fixed
     // uniform draw and relocate a sample -- a discontinuity, not an accuracy problem); only the colour-producing pass runs in
     // the three-way split arithmetic.
-    const int dtype_coarse = (split_dtype(dtype) && !o->coarse_only && !o->hybrid_sampling) ? NERF_MLP_F32 : dtype;
+    // hybrid_sampling: the sampling pass itself runs in a split arithmetic (the render's own, or -- for an f32 render -- f16x2 where
+    // the network fits the f16 range, else bf16x3) and only the ill-conditioned rays are redone in f32.
+    const int dtype_coarse = o->hybrid_sampling ? (split_dtype(dtype) ? dtype : c->net[NERF_NET_COARSE].wstream_x2 ? NERF_MLP_F16X2 : NERF_MLP_BF16X3)
+                                                : (split_dtype(dtype) && !o->coarse_only) ? NERF_MLP_F32 : dtype;
     if (o->skip_empty != 0 && o->skip_empty != 1) return fail(c, NERF_ERR_INVALID, "skip_empty must be 0 or 1");
     if (o->skip_dead != 0 && o->skip_dead != 1) return fail(c, NERF_ERR_INVALID, "skip_dead must be 0 or 1");
     if (o->skip_dead && dtype == NERF_MLP_BF16) return fail(c, NERF_ERR_INVALID, "skip_dead is implemented for NERF_MLP_F32, NERF_MLP_BF16X3 and NERF_MLP_F16X2 only");
     const bool seq = o->skip_dead != 0;
     if (o->hybrid_sampling != 0 && o->hybrid_sampling != 1) return fail(c, NERF_ERR_INVALID, "hybrid_sampling must be 0 or 1");
-    if (o->hybrid_sampling && !(seq && split_dtype(dtype) && !o->coarse_only))
-        return fail(c, NERF_ERR_INVALID, "hybrid_sampling needs skip_dead = 1, mlp_dtype NERF_MLP_BF16X3 or NERF_MLP_F16X2, and a hierarchical render");
+    if (o->hybrid_sampling && !(seq && !o->coarse_only))
+        return fail(c, NERF_ERR_INVALID, "hybrid_sampling needs skip_dead = 1 (mlp_dtype F32, BF16X3 or F16X2) and a hierarchical render");
     if (!c->net[NERF_NET_COARSE].loaded) return fail(c, NERF_ERR_STATE, "coarse network not loaded");
     if (!o->coarse_only && !c->net[NERF_NET_FINE].loaded) return fail(c, NERF_ERR_STATE, "fine network not loaded");
     if (dtype == NERF_MLP_F16X2 && (!c->net[o->coarse_only ? NERF_NET_COARSE : NERF_NET_FINE].wstream_x2 ||

@@ -154,7 +154,14 @@ def test_hybrid_sampling(renderer, native, samples):
         s1 = native.render_image(renderer.coarse, renderer.fine, cam, 128, seed=1, dtype="f16x2", skip_dead=True, hybrid_sampling=True)
         assert abs(psnr(s1, A["image"]) - gates["cpu_seed1_vs_A"]) <= 0.1
     # argument errors
-    for kw in ({"dtype": "f32", "skip_dead": True}, {"dtype": "f16x2"}, {"dtype": "f16x2", "skip_dead": True, "coarse_only": True}):
+    # an f32 render may use it too: f16x2 sampling pass + f32 redo, exact-f32 fine pass
+    f32d = native.render_image(renderer.coarse, renderer.fine, cam, 128, seed=0, crop=crop, skip_dead=True)
+    f32h, st = native.render_image(renderer.coarse, renderer.fine, cam, 128, seed=0, crop=crop, skip_dead=True, hybrid_sampling=True, return_stats=True)
+    d = np.abs(f32h - f32d)
+    print(f"f32 fine pass + hybrid sampling vs the f32 frame (crop): max {d.max():.2e} mean {d.mean():.2e}; redone {st.n_hybrid_rays / st.n_rays:.3f}")
+    _gate1(f32h, g["image"])
+    assert d.max() <= 1e-4 and d.mean() <= 2e-6 and st.n_hybrid_rays > 0
+    for kw in ({"dtype": "bf16", "skip_dead": True}, {"dtype": "f16x2"}, {"dtype": "f16x2", "skip_dead": True, "coarse_only": True}):
         with pytest.raises(native.NerfError) as e:
             native.render_image(renderer.coarse, renderer.fine, cam, 128, crop=(0, 0, 8, 8), hybrid_sampling=True, **kw)
-        assert e.value.code == -1 and "hybrid_sampling needs" in e.value.msg
+        assert e.value.code == -1 and ("hybrid_sampling needs" in e.value.msg or "skip_dead is implemented" in e.value.msg)
