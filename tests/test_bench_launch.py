@@ -22,7 +22,7 @@ def _run(n, argv, timeout=120):
     return subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=timeout, env=env)
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])          # 8 = the driver's largest scaling run
 def test_launch_ranks_relays_rank0_json(world):
     p = _run(world, ["--steps", "1"])
     assert p.returncode == 0, p.stderr
