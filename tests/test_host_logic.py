@@ -361,3 +361,16 @@ def test_loader_rejects_a_directory_named_like_a_tensor(native, tmp_path):
     os.remove(d / "dense2_bias.bin"); os.mkdir(d / "dense2_bias.bin")
     rc, msg = _check(native, d)
     assert rc == -2 and "read tensor" in msg and "dense2_bias" in msg
+
+
+def test_render_opts_mirror_maps_every_field(native):
+    """The Python mirror of nerf_render_opts: every option reaches its C field (no device needed)."""
+    from nerf_rs_amd.api import RenderOpts, _DTYPES
+    assert (_DTYPES["f32"], _DTYPES["bf16"], _DTYPES["bf16x3"], _DTYPES["f16x2"]) == (0, 1, 2, 3)
+    o = RenderOpts(n_coarse=40, n_fine=50, coarse_only=True, crop=(1, 2, 3, 4), ssaa=2, seed=(1 << 40) + 7, dtype="f16x2",
+                   skip_empty=True, skip_dead=True, hybrid_sampling=True).to_c()
+    got = {name: getattr(o, name) for name, _ in type(o)._fields_}
+    assert got == {"n_coarse": 40, "n_fine": 50, "coarse_only": 1, "crop_x0": 1, "crop_y0": 2, "crop_w": 3, "crop_h": 4, "ssaa": 2,
+                   "seed": (1 << 40) + 7, "mlp_dtype": 3, "skip_empty": 1, "skip_dead": 1, "hybrid_sampling": 1}
+    z = RenderOpts().to_c()
+    assert (z.n_coarse, z.n_fine, z.mlp_dtype, z.skip_empty, z.skip_dead, z.hybrid_sampling, z.crop_w, z.ssaa) == (64, 128, 0, 0, 0, 0, 0, 1)
