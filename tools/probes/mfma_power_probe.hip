@@ -1,88 +1,154 @@
-// Power/clock probe: the same bf16 FLOPs per wave as v_mfma_f32_32x32x16_bf16 (variant 0) or v_mfma_f32_16x16x32_bf16
-// (variant 1), operands re-read from LDS (3 ds_read_b128 per 6 / 12 MFMAs, as in mlp_kernel_bf16x3.hip), random data.
-// Prints achieved PFLOP/s and the in-kernel clock.  hipcc --offload-arch=gfx950 -O3 -o mfma_power_probe mfma_power_probe.hip
+// mfma_power_probe.hip -- what the 16-bit matrix cores of THIS MI355X deliver on random operands, with nothing else in the loop.
+//
+// The 16-bit MLP kernels (bf16v2, bf16x3, f16x2) sit at ~0.59-0.67 of the nominal 2.5 PFLOP/s while their in-kernel clock falls to
+// ~2.0 GHz.  This probe prices the ceiling: bare MFMA loops (operands in registers, one wave per SIMD, one workgroup per CU,
+// random data so that the datapath toggles) for both shapes and both 16-bit types, plus the same loops with the A operand re-read
+// from LDS every step (what a weight-streaming kernel has to do).  Reports TFLOP/s, fraction of 2.5 PF and the in-kernel clock
+// (delta s_memtime / delta s_memrealtime x 100 MHz; MI355X_MICROARCH.md "DVFS give-back" item 6).
+//
+// build: hipcc --offload-arch=gfx950 -O3 -o mfma_power_probe mfma_power_probe.hip ; run: ./mfma_power_probe [seconds per variant]
 #include <hip/hip_runtime.h>
-#include <cstdio>
-#include <cstdlib>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+#include <algorithm>
 #include <vector>
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
-template <int VARIANT>
-__global__ __launch_bounds__(256, 1) void probe(const u32x4 *src, float *out, unsigned long long *clk, int iters) {
-    __shared__ u32x4 lds[4096]; // 64 KiB
-    for (int i = threadIdx.x; i < 4096; i += 256) lds[i] = src[i];
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s:%d %s\n", __FILE__, __LINE__, hipGetErrorString(e_)); exit(1); } } while (0)
+
+enum { V_BF16_32 = 0, V_BF16_16 = 1, V_F16_32 = 2, V_F16_16 = 3 };
+
+template <int V> struct Op;
+template <> struct Op<V_BF16_32> { using T = bf16x8; static constexpr bool k32 = true; };
+template <> struct Op<V_BF16_16> { using T = bf16x8; static constexpr bool k32 = false; };
+template <> struct Op<V_F16_32> { using T = f16x8; static constexpr bool k32 = true; };
+template <> struct Op<V_F16_16> { using T = f16x8; static constexpr bool k32 = false; };
+
+__device__ __forceinline__ f32x16 mm32(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f32x16 mm32(f16x8 a, f16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f32x4 mm16(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f32x4 mm16(f16x8 a, f16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+
+// Output tile per wave is 64 x 64 in both shapes: 2 x 2 tiles of 32x32 (4 MFMAs of 32 768 FLOP) or 4 x 4 tiles of 16x16 (16 MFMAs of
+// 16 384 FLOP) per k-step: 131 072 / 262 144 FLOP per step.  NK k-steps of operands are held in registers and cycled through.
+// LDSA: the A fragments come from LDS (ds_read_b128, lane-linear) every step instead of from registers.
+template <int V, bool LDSA>
+__global__ __launch_bounds__(256, 1) void probe(const u32x4 *src, float *sink, unsigned long long *stamps, int iters) {
+    using T = typename Op<V>::T;
+    constexpr bool K32 = Op<V>::k32;
+    constexpr int NA = K32 ? 2 : 4, NK = 4;
+    __shared__ u32x4 lds[NK * 4 * 64 * 4]; // [k][frag][lane] per wave
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    T a[NK][NA], b[NK][NA];
+    for (int k = 0; k < NK; ++k)
+        for (int i = 0; i < NA; ++i) {
+            const u32x4 va = src[((blockIdx.x * 4 + wave) * NK * 8 + k * 8 + i) * 64 + lane];
+            const u32x4 vb = src[((blockIdx.x * 4 + wave) * NK * 8 + k * 8 + 4 + i) * 64 + lane];
+            a[k][i] = __builtin_bit_cast(T, va);
+            b[k][i] = __builtin_bit_cast(T, vb);
+            lds[((wave * NK + k) * 4 + i) * 64 + lane] = va;
+        }
     __syncthreads();
-    const int lane = threadIdx.x & 63;
-    u32x4 b1 = src[lane], b2 = src[64 + lane], b3 = src[128 + lane];
-    f32x16 acc[8];
-    for (int t = 0; t < 8; ++t) for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-    const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    f32x16 c32[2][2];
+    f32x4 c16[4][4];
+    for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int r = 0; r < 16; ++r) c32[i][j][r] = 0.f;
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) for (int r = 0; r < 4; ++r) c16[i][j][r] = 0.f;
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int base = ((it * 8 + u) * 192) & 4095;
-            const u32x4 a1 = lds[(base + lane) & 4095], a2 = lds[(base + 64 + lane) & 4095], a3 = lds[(base + 128 + lane) & 4095];
-            const bf16x8 A1 = __builtin_bit_cast(bf16x8, a1), A2 = __builtin_bit_cast(bf16x8, a2), A3 = __builtin_bit_cast(bf16x8, a3);
-            const bf16x8 B1 = __builtin_bit_cast(bf16x8, b1), B2 = __builtin_bit_cast(bf16x8, b2), B3 = __builtin_bit_cast(bf16x8, b3);
-            if (VARIANT == 0) {
-                acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A3, B1, acc[u], 0, 0, 0);
-                acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A2, B2, acc[u], 0, 0, 0);
-                acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, B3, acc[u], 0, 0, 0);
-                acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A2, B1, acc[u], 0, 0, 0);
-                acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, B2, acc[u], 0, 0, 0);
-                acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, B1, acc[u], 0, 0, 0);
-            } else {
-                f32x4 p = {acc[u][0], acc[u][1], acc[u][2], acc[u][3]}, q = {acc[u][4], acc[u][5], acc[u][6], acc[u][7]};
+        for (int k = 0; k < NK; ++k) {
+            T av[NA];
 #pragma unroll
-                for (int k = 0; k < 2; ++k) { // the same FLOPs: 2 x 16x16x32 per 32x32x16
-                    f32x4 &c = k ? q : p;
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A3, B1, c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A2, B2, c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A1, B3, c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A2, B1, c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A1, B2, c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A1, B1, c, 0, 0, 0);
-                }
-                acc[u][0] = p[0]; acc[u][1] = p[1]; acc[u][2] = p[2]; acc[u][3] = p[3];
-                acc[u][4] = q[0]; acc[u][5] = q[1]; acc[u][6] = q[2]; acc[u][7] = q[3];
+            for (int i = 0; i < NA; ++i) {
+                if (LDSA) av[i] = __builtin_bit_cast(T, lds[((wave * NK + k) * 4 + i) * 64 + lane]);
+                else av[i] = a[k][i];
             }
+#pragma unroll
+            for (int i = 0; i < NA; ++i)
+#pragma unroll
+                for (int j = 0; j < NA; ++j) {
+                    if constexpr (K32) c32[i][j] = mm32(av[i], b[k][j], c32[i][j]);
+                    else c16[i][j] = mm16(av[i], b[k][j], c16[i][j]);
+                }
         }
+        // keep the accumulators bounded without leaving the matrix pipe idle for long: nothing (f32 does not overflow in this many steps
+        // with operands of magnitude <= 2^-4: |sum| <= iters * NK * 16 * 2^-8)
     }
-    const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
     float s = 0.f;
-    for (int t = 0; t < 8; ++t) for (int r = 0; r < 16; ++r) s += acc[t][r];
-    out[blockIdx.x * 256 + threadIdx.x] = s;
-    if (threadIdx.x == 0) { clk[2 * blockIdx.x] = c1 - c0; clk[2 * blockIdx.x + 1] = r1 - r0; }
+    for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int r = 0; r < 16; ++r) s += c32[i][j][r];
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) for (int r = 0; r < 4; ++r) s += c16[i][j][r];
+    sink[blockIdx.x * 256 + threadIdx.x] = s;
+    if (threadIdx.x == 0) { stamps[2 * blockIdx.x] = t1 - t0; stamps[2 * blockIdx.x + 1] = r1 - r0; }
 }
 
-int main() {
-    const int iters = 40000, nb = 256;
-    std::vector<unsigned int> h(4096 * 4);
-    srand(1);
-    for (auto &v : h) { // random bf16 pairs of moderate magnitude
-        unsigned short a = (unsigned short)(0x3c00 + (rand() & 0x3ff) + ((rand() & 1) << 15)), b = (unsigned short)(0x3c00 + (rand() & 0x3ff) + ((rand() & 1) << 15));
-        v = (unsigned int)a | ((unsigned int)b << 16);
-    }
-    u32x4 *src; float *out; unsigned long long *clk;
-    hipMalloc(&src, h.size() * 4); hipMalloc(&out, nb * 256 * 4); hipMalloc(&clk, nb * 16);
-    hipMemcpy(src, h.data(), h.size() * 4, hipMemcpyHostToDevice);
-    for (int variant = 0; variant < 2; ++variant)
-        for (int rep = 0; rep < 3; ++rep) {
-            hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-            hipEventRecord(e0);
-            if (variant == 0) hipLaunchKernelGGL(probe<0>, dim3(nb), dim3(256), 0, 0, src, out, clk, iters);
-            else hipLaunchKernelGGL(probe<1>, dim3(nb), dim3(256), 0, 0, src, out, clk, iters);
-            hipEventRecord(e1); hipEventSynchronize(e1);
-            float ms; hipEventElapsedTime(&ms, e0, e1);
-            std::vector<unsigned long long> c(nb * 2);
-            hipMemcpy(c.data(), clk, nb * 16, hipMemcpyDeviceToHost);
-            const double mhz = 100.0 * (double)c[0] / (double)c[1];
-            const double flops = (double)nb * 4 * iters * 8 * 6 * 32768.0; // 6 x 32x32x16 per unit, 8 units per iteration
-            printf("variant %d (%s): %.1f ms  %.3f PFLOP/s  clock %.0f MHz  cycles per 32x32x16-equivalent %.1f\n", variant,
-                   variant ? "16x16x32" : "32x32x16", ms, flops / (ms * 1e-3) / 1e15, mhz, (double)c[0] / ((double)iters * 48));
-        }
+static uint16_t rnd16(uint32_t &st, bool bf) {
+    st = st * 1664525u + 1013904223u;
+    // random sign, exponent in [2^-8, 2^-4), random mantissa: every operand bit toggles
+    const uint32_t sign = (st >> 31) & 1u, e = (st >> 28) & 3u, man = (st >> 8);
+    if (bf) return (uint16_t)((sign << 15) | ((127u - 8u + e) << 7) | (man & 0x7fu));
+    return (uint16_t)((sign << 15) | ((15u - 8u + e) << 10) | (man & 0x3ffu));
+}
+
+template <int V, bool LDSA>
+static void run(const char *name, int n_cus, double seconds, bool zeros) {
+    constexpr bool K32 = Op<V>::k32;
+    const bool bf = (V == V_BF16_32 || V == V_BF16_16);
+    const size_t n_vec = (size_t)n_cus * 4 * 4 * 8 * 64;
+    std::vector<uint16_t> h(n_vec * 8);
+    uint32_t st = 12345u + V;
+    for (auto &x : h) x = zeros ? 0 : rnd16(st, bf);
+    u32x4 *d_src; float *d_sink; unsigned long long *d_st;
+    CK(hipMalloc((void **)&d_src, n_vec * 16)); CK(hipMalloc((void **)&d_sink, (size_t)n_cus * 256 * 4)); CK(hipMalloc((void **)&d_st, (size_t)n_cus * 16));
+    CK(hipMemcpy(d_src, h.data(), n_vec * 16, hipMemcpyHostToDevice));
+    const int iters = 20000; // x 4 k-steps
+    const double flop = (double)n_cus * 4 * iters * 4 * (K32 ? 4 * 32768.0 : 16 * 16384.0);
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    // warm up for `seconds`, then time the same number of launches again
+    probe<V, LDSA><<<n_cus, 256>>>(d_src, d_sink, d_st, iters);
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0)); probe<V, LDSA><<<n_cus, 256>>>(d_src, d_sink, d_st, iters); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+    float ms1 = 0; CK(hipEventElapsedTime(&ms1, e0, e1));
+    const int reps = std::max(2, (int)(seconds * 1000.0 / ms1));
+    for (int r = 0; r < reps; ++r) probe<V, LDSA><<<n_cus, 256>>>(d_src, d_sink, d_st, iters);
+    CK(hipEventRecord(e0));
+    for (int r = 0; r < reps; ++r) probe<V, LDSA><<<n_cus, 256>>>(d_src, d_sink, d_st, iters);
+    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+    float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1));
+    std::vector<unsigned long long> sv((size_t)n_cus * 2);
+    CK(hipMemcpy(sv.data(), d_st, sv.size() * 8, hipMemcpyDeviceToHost));
+    std::vector<double> mhz;
+    for (int i = 0; i < n_cus; ++i) if (sv[2 * i + 1]) mhz.push_back((double)sv[2 * i] / (double)sv[2 * i + 1] * 100.0);
+    std::sort(mhz.begin(), mhz.end());
+    const double tf = flop * reps / (ms * 1e-3) / 1e12;
+    const double cyc_per_step = mhz.empty() ? 0 : (ms * 1e-3 / reps) * mhz[mhz.size() / 2] * 1e6 / ((double)iters * 4);
+    printf("{\"variant\": \"%s\", \"data\": \"%s\", \"tflops\": %.1f, \"frac_of_2500\": %.3f, \"clock_mhz_median\": %.0f, \"cycles_per_kstep\": %.1f, \"ms_per_launch\": %.2f, \"launches\": %d}\n",
+           name, zeros ? "zeros" : "random", tf, tf / 2500.0, mhz.empty() ? 0.0 : mhz[mhz.size() / 2], cyc_per_step, ms / reps, reps);
+    fflush(stdout);
+    CK(hipFree(d_src)); CK(hipFree(d_sink)); CK(hipFree(d_st));
+}
+
+int main(int argc, char **argv) {
+    const double seconds = argc > 1 ? atof(argv[1]) : 2.5;
+    hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0));
+    const int n_cus = prop.multiProcessorCount;
+    printf("{\"device\": \"%s\", \"cus\": %d}\n", prop.gcnArchName, n_cus);
+    run<V_BF16_32, false>("bf16 32x32x16 regs", n_cus, seconds, false);
+    run<V_BF16_16, false>("bf16 16x16x32 regs", n_cus, seconds, false);
+    run<V_F16_32, false>("f16 32x32x16 regs", n_cus, seconds, false);
+    run<V_F16_16, false>("f16 16x16x32 regs", n_cus, seconds, false);
+    run<V_BF16_32, true>("bf16 32x32x16 A from LDS", n_cus, seconds, false);
+    run<V_BF16_16, true>("bf16 16x16x32 A from LDS", n_cus, seconds, false);
+    run<V_F16_32, true>("f16 32x32x16 A from LDS", n_cus, seconds, false);
+    run<V_F16_16, true>("f16 16x16x32 A from LDS", n_cus, seconds, false);
+    run<V_BF16_32, false>("bf16 32x32x16 regs", n_cus, seconds, true);
+    run<V_BF16_16, false>("bf16 16x16x32 regs", n_cus, seconds, true);
     return 0;
 }
