@@ -25,20 +25,24 @@ PEAK_FP32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, "Peak F
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # same table, "Peak BF16/FP16 MFMA ~2.5 PF dense"
 
 
+PROFILE_ROUND = "r03"  # the round whose committed rocprofv3 summaries (profiles/r03*) describe the kernels this bench.py runs
+
+
 def pmc_traffic_bytes(kernel_prefix="void nerf_mlp_kernel<true"):
-    """HBM bytes per launch of the fine-MLP kernel from the committed rocprofv3 PMC passes (profiles/*_pmc_summary.csv:
-    separate FETCH_SIZE / WRITE_SIZE runs; FETCH_SIZE doubled per the gfx950 note in MI355X_MICROARCH.md).  The kernel is
-    MFMA-bound; this is reported for completeness (algorithmic: 20 B/point in+out = 2.46 GB per 122.88 M-point launch).
-    The summary of the latest round (by file name) that holds the kernel wins."""
+    """HBM bytes per launch of the dominant kernel from THIS round's committed rocprofv3 PMC passes (profiles/r03*_pmc_summary.csv:
+    separate FETCH_SIZE / WRITE_SIZE runs; FETCH_SIZE doubled per the gfx950 note in MI355X_MICROARCH.md).  PMC counters cannot be
+    collected from inside the run, so this is the profile of the same command, not a per-run measurement; there is no fallback to an
+    earlier round's profile: without a current summary for the selected kernel `traffic` is null and the line says why.
+    Returns (bytes or None, source file or None, reason or None)."""
     import csv
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.csv")), reverse=True)  # r02_* before r01_*: newest round first
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", PROFILE_ROUND + "*_pmc_summary.csv")))
     for f in files:
         for row in csv.DictReader(open(f)):
             if row["kernel"].startswith(kernel_prefix) and float(row.get("FETCH_SIZE", 0) or 0) > 0:
                 n = max(int(row["dispatches"]), 1)
-                return (2.0 * float(row["FETCH_SIZE"]) + float(row.get("WRITE_SIZE", 0) or 0)) * 1024.0 / n, os.path.relpath(f, ROOT)
-    return None, None
+                return (2.0 * float(row["FETCH_SIZE"]) + float(row.get("WRITE_SIZE", 0) or 0)) * 1024.0 / n, os.path.relpath(f, ROOT), None
+    return None, None, f"no profiles/{PROFILE_ROUND}*_pmc_summary.csv row for kernel '{kernel_prefix}...' (PMC passes of this round not committed for it)"
 
 
 def host_cores():
@@ -107,6 +111,10 @@ def launch_ranks(n, argv, script=None):
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
     procs = []
+    # HSA_ENABLE_IPC_MODE_LEGACY=0: RCCL's intra-node transport shares device buffers between the rank processes through HIP IPC
+    # handles; the host driver of this pool supports only the dmabuf flavour, and with the legacy mode left on
+    # `hipIpcGetMemHandle` fails with "invalid argument" as soon as two ranks on different GPUs connect.  The image exports the
+    # variable already; it is passed on explicitly (an existing value wins) so that the ranks never depend on the caller's shell.
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
@@ -220,6 +228,8 @@ def main():
     weak = args.scaling == "weak" and world > 1
     view_seed = args.seed + (rank if weak else 0)  # weak scaling: rank r renders view r (its own sample-jitter stream)
 
+    marks = []  # N > 1: per-step (render, gather) marks of this rank
+
     def step():
         if not use_dist or weak:
             N.render_image(r.coarse, r.fine, cam, args.fine, seed=view_seed, ssaa=args.ssaa, dtype=args.dtype,
@@ -227,7 +237,8 @@ def main():
                            device_out=frame.data_ptr(), stream=stream)
             return frame
         return N.render_image_distributed(r.coarse, r.fine, cam, args.fine, seed=args.seed, ssaa=args.ssaa, dtype=args.dtype,
-                                          skip_empty=args.skip_empty, skip_dead=args.skip_dead, group=data_group, return_tensor=True)
+                                          skip_empty=args.skip_empty, skip_dead=args.skip_dead, hybrid_sampling=args.hybrid_sampling,
+                                          group=data_group, return_tensor=True, timings=marks)
 
     def fence():
         if use_dist:
@@ -238,6 +249,7 @@ def main():
         step()
     fence()
     r.kernel_time_query(reset=True)
+    marks.clear()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
@@ -249,6 +261,16 @@ def main():
     if use_dist:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
+    # N > 1: attribute the step to render vs gather, per rank (events recorded inside the timed region, read here)
+    per_rank = None
+    if use_dist and marks:
+        mine = [m.ms() for m in marks]
+        v = torch.tensor([sum(a for a, _ in mine) / len(mine), sum(b for _, b in mine) / len(mine), ms_dom / max(n_dom, 1)],
+                         dtype=torch.float64, device=tmax.device)
+        allv = [torch.empty_like(v) for _ in range(world)]
+        dist.all_gather(allv, v)
+        cols = list(zip(*[t.tolist() for t in allv]))
+        per_rank = {k: {"max": max(c), "min": min(c), "by_rank": list(c)} for k, c in zip(("ms_render", "ms_gather", "ms_dominant_kernel_per_launch"), cols)}
     skipped_per_launch = 0
     if args.skip_empty and world == 1:  # one extra untimed frame with stats: the skip count is deterministic per frame
         st = N.render_image(r.coarse, r.fine, cam, args.fine, seed=args.seed, ssaa=args.ssaa, dtype=args.dtype,
@@ -443,11 +465,10 @@ def main():
         if dead_stats is not None:  # dominant launch = the ray-sequential fine trunk (dense0..7 + alpha on the samples in front of the cut)
             flops_dom = (n_dom / max(dead_stats.n_passes, 1)) * dead_stats.n_exec_fine_trunk * N.FLOP_PER_POINT_SIGMA  # one launch per pass
         ach = mfma_per_flop * flops_dom / (ms_dom * 1e-3) / 1e12 if ms_dom > 0 else 0.0
-        traffic, traffic_src = pmc_traffic_bytes("void nerf_mlp_kernel_bf16v2<true" if bf16 else
-                                                 "void nerf_mlp_kernel_bf16x3<true" if x3 else "void nerf_mlp_kernel_f16x2<true" if x2 else
-                                                 "void nerf_trunk_seq_kernel<true" if args.skip_dead else "void nerf_mlp_kernel<true")
-        if args.skip_dead and split:
-            traffic, traffic_src = pmc_traffic_bytes(f"void nerf_trunk_seq_kernel_{sfx}<true")
+        traffic, traffic_src, traffic_why = pmc_traffic_bytes(
+            (f"void nerf_trunk_seq_kernel_{sfx}<" if split else "void nerf_trunk_seq_kernel<") if args.skip_dead else
+            "void nerf_mlp_kernel_bf16v2<true" if bf16 else "void nerf_mlp_kernel_bf16x3<true" if x3 else
+            "void nerf_mlp_kernel_f16x2<true" if x2 else "void nerf_mlp_kernel<true")
         line = {  # noqa: E501
             "metric": "rays/sec, lego 800x800 (64 coarse + 128 fine samples per ray)", "value": value, "unit": "rays/s",
             "n_gpus": world, "ranks": dist.get_world_size() if use_dist else 1,
@@ -466,7 +487,9 @@ def main():
                                    f"samples/ray, {args.dtype}, {world}xMI355X" +
                                    ("" if world == 1 else ", one frame per rank, no collective" if weak else ", row bands + RCCL all-gather"),
                        "rays_per_step": n_rays, "flop_per_ray": flop_ray, "seed": args.seed,
-                       "frame": "left in HBM inside the timed region (value excludes PCIe)",
+                       "frame": "left in HBM inside the timed region: `value` excludes the 7.68 MB device-to-host copy of the frame, as the bench "
+                                "contract requires (inputs and outputs resident in HBM).  This supersedes BASELINE.md section 4's wording (\"includes "
+                                "the device-to-host copy of the image\"); the PCIe-inclusive rate is reported beside it as rays_per_s_including_d2h",
                        "d2h_ms_per_frame": d2h_ms,
                        "rays_per_s_including_d2h": (n_rays / (dt / args.steps + 1e-3 * d2h_ms)) if d2h_ms is not None else None,
                        "skip_empty": bool(args.skip_empty), "skip_dead": bool(args.skip_dead), "hybrid_sampling": bool(args.hybrid_sampling),
@@ -474,8 +497,9 @@ def main():
                        "whole_job_fraction_of_mfma_roofline": mfma_per_flop * value * flop_ray / (world * peak * 1e12)},  # per-GPU average
             "roofline": {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
                          "frac": ach / peak, "traffic": traffic,
-                         "traffic_source": (f"HBM bytes per launch from the committed rocprofv3 PMC passes ({traffic_src}; 2 x FETCH_SIZE + WRITE_SIZE "
-                                            "in separate --pmc runs), not re-measured in this run; algorithmic: 20 B/point") if traffic_src else None,
+                         "traffic_source": (f"HBM bytes per launch from this round's committed rocprofv3 PMC passes of the same command ({traffic_src}; "
+                                            "2 x FETCH_SIZE + WRITE_SIZE in separate --pmc runs; counters cannot be read from inside the run); "
+                                            "algorithmic: 20 B/point") if traffic_src else traffic_why,
                          "kernel": ((f"nerf_trunk_seq_kernel_{sfx}" if split else "nerf_trunk_seq_kernel") + "<EXPORT=true> (fine network, ray-sequential trunk; executed flops)"
                                     if dead_stats is not None else
                                     ("nerf_mlp_kernel_bf16v2" if bf16 else "nerf_mlp_kernel_bf16x3" if x3 else "nerf_mlp_kernel_f16x2" if x2 else "nerf_mlp_kernel") +
@@ -484,6 +508,8 @@ def main():
                          "points_per_launch": pts_dom // max(n_dom, 1),
                          "flop_per_point": N.FLOP_PER_POINT_SIGMA if dead_stats is not None else N.FLOP_PER_POINT_FULL},
         }
+        if per_rank is not None:
+            line["per_rank"] = per_rank  # max/min over ranks: render (HIP events around the band render), gather (events around the collective)
         if split:
             line["roofline"]["note"] = (f"achieved/peak price the EXECUTED 16-bit MFMA flops ({mfma_per_flop:.0f} per algorithmic f32 flop) against the "
                                         "bf16/f16 peak; f32_equivalent_tflops = algorithmic f32 flops / time")

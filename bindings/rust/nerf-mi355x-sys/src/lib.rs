@@ -95,6 +95,7 @@ extern "C" {
     pub fn nerf_load_network_tensors(ctx: *mut nerf_ctx, which: c_int, n: c_int, names: *const *const c_char,
                                      dims: *const i64, data: *const *const f32) -> c_int;
     pub fn nerf_check_network_dir(dir: *const c_char) -> c_int;
+    pub fn nerf_check_network_blob(blob_path: *const c_char) -> c_int;
     pub fn nerf_pack_network_dir(dir: *const c_char, blob_path: *const c_char) -> c_int;
     pub fn nerf_load_network_blob(ctx: *mut nerf_ctx, which: c_int, blob_path: *const c_char) -> c_int;
     pub fn nerf_debug_pack_network_dir(dir: *const c_char, wstream: *mut f32, wstream_cap: usize, small: *mut f32,

@@ -139,6 +139,8 @@ int nerf_load_network_blob(nerf_ctx *ctx, int which, const char *blob_path);
 
 /* Host-only validation of a weight directory (same checks as nerf_load_network_dir, no device needed). */
 int nerf_check_network_dir(const char *dir);
+/* Host-only validation of a packed blob (same reader and checks as nerf_load_network_blob: magic, version, exact size). */
+int nerf_check_network_blob(const char *blob_path);
 /* Diagnostic: the packed device images of a weight directory (layout: nerf-rs_amd/csrc/mlp_layout.h).  Pass NULL
  * buffers to query the lengths (in floats).  Host-only. */
 int nerf_debug_pack_network_dir(const char *dir, float *wstream, size_t wstream_cap, float *small, size_t small_cap,
@@ -180,7 +182,10 @@ int nerf_render_image_device(nerf_ctx *ctx, const nerf_camera *cam, const nerf_r
  *   NERF_GATHER_HOST  each band is copied device -> host into its rows directly (no GPU-to-GPU traffic);
  *   NERF_GATHER_PEER  bands are copied GPU -> GPU over xGMI (hipMemcpyPeerAsync) into a frame on ctxs[0]'s device, then one D2H;
  *   NERF_GATHER_RCCL  ONE ncclAllGather of the bands (RCCL over xGMI; librccl is dlopen'ed on first use): the whole frame
- *                     ends up on every device, then one D2H from ctxs[0].  Needs distinct devices.
+ *                     ends up on every device, then one D2H from ctxs[0].  RCCL refuses two ranks on one device: when contexts
+ *                     share a device (single-GPU test boxes) the collective step is rehearsed as device-to-device copies into the
+ *                     same equal-slot buffers (same layout, stream ordering and ragged compaction); RCCL proper runs whenever
+ *                     the devices are distinct.
  * Synchronous.  per_ctx (n entries) may be NULL.  Several contexts may share a device (tests; no speed-up).  Not re-entrant:
  * calls that share a context -- or, with NERF_GATHER_RCCL, a device (the communicators are cached per device list) -- must not
  * overlap.  Errors of any band are reported on ctxs[0]. */

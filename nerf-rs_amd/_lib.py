@@ -39,7 +39,7 @@ class CStats(C.Structure):
                 ("n_exec_colour", C.c_uint64), ("n_hybrid_rays", C.c_uint64)]
 
 
-# name -> (restype, argtypes); kept in sync with include/nerf_mi355x.h (tests/test_abi.py checks the header)
+# name -> (restype, argtypes); kept in sync with include/nerf_mi355x.h (tests/test_host_logic.py::test_abi_exports_every_declared_symbol checks the header)
 PROTOTYPES = {
     "nerf_abi_version": (C.c_int, []),
     "nerf_abi_struct_sizes": (None, [C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
@@ -55,6 +55,7 @@ PROTOTYPES = {
     "nerf_camera_from_pose": (C.c_int, [f32p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int,
                                         C.POINTER(CCamera)]),
     "nerf_check_network_dir": (C.c_int, [C.c_char_p]),
+    "nerf_check_network_blob": (C.c_int, [C.c_char_p]),
     "nerf_debug_pack_network_dir": (C.c_int, [C.c_char_p, f32p, C.c_size_t, f32p, C.c_size_t, C.POINTER(C.c_size_t),
                                               C.POINTER(C.c_size_t)]),
     "nerf_debug_split_bf16x3": (C.c_int, [f32p, C.c_size_t, C.POINTER(C.c_uint16)]),

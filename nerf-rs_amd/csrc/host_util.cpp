@@ -73,7 +73,9 @@ static int take(std::map<std::string, Tensor> &params, const std::string &name, 
         }
         L.b = std::move(t.data);
     } else {
-        if (t.dims.size() != 2 || (size_t)(t.dims[0] * t.dims[1]) != t.data.size() || t.dims[0] != K || t.dims[1] != N) {
+        // compare the dimensions first: their product is only formed for the expected (small) values -- a shapes.txt line
+        // "dense0_kernel 99999999999999 99999999999999" overflowed int64 here (found by the host-asan build, tests/test_host_asan.py)
+        if (t.dims.size() != 2 || t.dims[0] != K || t.dims[1] != N || (size_t)K * (size_t)N != t.data.size()) {
             snprintf(buf, sizeof buf, "matrix dims mismatch for %s: expected [%d, %d], file has %zu values", name.c_str(), K, N, t.data.size());
             err = buf;
             return NERF_ERR_SHAPE;

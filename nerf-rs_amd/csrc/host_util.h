@@ -53,6 +53,11 @@ int camera_from_json(const std::string &path, int width, int height, nerf_camera
 void camera_basis(const nerf_camera &cam, float r[3], float u[3], float f[3], float *sx, float *sy);
 
 void quantize_rgb8(const float *rgb, size_t n_pixels, uint8_t *out);
+
+// nerf_host_api.cpp: error message of context-free calls (nerf_last_error(NULL)), per thread; the packed-blob reader
+int fail_noctx(int code, const std::string &msg);
+const char *last_error_noctx();
+int read_blob_file(const std::string &path, std::vector<float> &wstream, std::vector<float> &small, std::string &err);
 int save_ppm(const std::string &path, int width, int height, const float *rgb, std::string &err);
 
 } // namespace nerfhost

@@ -31,12 +31,9 @@ using namespace nerfint;
 
 namespace nerfint {
 
-thread_local std::string g_err; // context-free calls
-
 int fail(nerf_ctx *c, int code, const std::string &msg) {
     if (c) c->err = msg;
-    g_err = msg;
-    return code;
+    return nerfhost::fail_noctx(code, msg); // also recorded for nerf_last_error(NULL) of this thread
 }
 
 } // namespace nerfint
@@ -76,9 +73,12 @@ int nerfint::ensure_bytes(nerf_ctx *c, void **p, size_t *cur, size_t need) {
 
 namespace {
 
-int ensure_workspace(nerf_ctx *c, size_t rays, size_t nc, size_t m) {
-    if (rays <= c->ws_rays && nc <= c->ws_nc && m <= c->ws_m) return NERF_OK;
+// The coarse network's colours exist only in a coarse_only render (the reference discards them otherwise, src/lib.rs:404):
+// their buffer (rays x nc x 3 floats, 492 MB for an 800x800 pass) is allocated on first such use only.
+int ensure_workspace(nerf_ctx *c, size_t rays, size_t nc, size_t m, bool need_rgbc) {
+    if (rays <= c->ws_rays && nc <= c->ws_nc && m <= c->ws_m && (!need_rgbc || c->d_rgbc)) return NERF_OK;
     rays = std::max(rays, c->ws_rays); nc = std::max(nc, c->ws_nc); m = std::max(m, c->ws_m);
+    need_rgbc = need_rgbc || c->d_rgbc != nullptr;
     HIP_TRY(c, hipDeviceSynchronize());
     float **ptrs[] = {&c->d_dirs, &c->d_tc, &c->d_sc, &c->d_rgbc, &c->d_tf, &c->d_sf, &c->d_rgbf};
     for (auto p : ptrs) if (*p) { HIP_TRY(c, hipFree(*p)); *p = nullptr; }
@@ -86,7 +86,7 @@ int ensure_workspace(nerf_ctx *c, size_t rays, size_t nc, size_t m) {
     HIP_TRY(c, hipMalloc((void **)&c->d_dirs, rays * 3 * sizeof(float)));
     HIP_TRY(c, hipMalloc((void **)&c->d_tc, rays * nc * sizeof(float)));
     HIP_TRY(c, hipMalloc((void **)&c->d_sc, rays * nc * sizeof(float)));
-    HIP_TRY(c, hipMalloc((void **)&c->d_rgbc, rays * nc * 3 * sizeof(float)));
+    if (need_rgbc) HIP_TRY(c, hipMalloc((void **)&c->d_rgbc, rays * nc * 3 * sizeof(float)));
     HIP_TRY(c, hipMalloc((void **)&c->d_tf, rays * m * sizeof(float)));
     HIP_TRY(c, hipMalloc((void **)&c->d_sf, rays * m * sizeof(float)));
     HIP_TRY(c, hipMalloc((void **)&c->d_rgbf, rays * m * 3 * sizeof(float)));
@@ -299,7 +299,7 @@ int nerfint::render_device(nerf_ctx *c, const nerf_camera *cam, const nerf_rende
     }
     if ((size_t)RW > pass_cap && (size_t)RW * M > (size_t)0x3fffffff) return fail(c, NERF_ERR_INVALID, "ray row too wide for one pass");
     const size_t rows_per_pass = std::max<size_t>(1, std::min<size_t>(RH, pass_cap / (size_t)RW));
-    if ((rc = ensure_workspace(c, rows_per_pass * RW, nc, M))) return rc;
+    if ((rc = ensure_workspace(c, rows_per_pass * RW, nc, M, o->coarse_only != 0))) return rc;
     float *ray_out = d_out;
     if (s > 1) {
         if ((rc = ensure_bytes(c, (void **)&c->d_rayfb, &c->rayfb_floats, (size_t)RW * RH * 3 * sizeof(float)))) return rc;
@@ -378,7 +378,7 @@ int nerfint::render_device(nerf_ctx *c, const nerf_camera *cam, const nerf_rende
         // coarse network: sigma only unless its colours are composited (reference discards them, src/lib.rs:404)
         a.wstream = stream_of(NC, dtype_coarse); a.small_params = NC.small;
         a.n_points = n_rays * nc; a.samples_per_ray = nc; a.t = c->d_tc;
-        a.sigma_out = c->d_sc; a.rgb_out = c->d_rgbc;
+        a.sigma_out = c->d_sc; a.rgb_out = o->coarse_only ? c->d_rgbc : nullptr; // sigma-only launch otherwise
         a.skip_empty = o->skip_empty; a.skip_counter = o->skip_empty ? c->d_skip : nullptr; // only full kernels look at it
         if (seq) {
             if ((rc = seq_pass(NC, dtype_coarse, nc, c->d_tc, c->d_sc, o->coarse_only ? c->d_rgbc : nullptr, 3 * (int)passes, o->coarse_only ? 1 : 0))) return rc;
@@ -532,7 +532,7 @@ void nerf_abi_struct_sizes(size_t *camera, size_t *render_opts, size_t *stats) {
     if (stats) *stats = sizeof(nerf_stats);
 }
 
-const char *nerf_last_error(const nerf_ctx *ctx) { return ctx ? ctx->err.c_str() : g_err.c_str(); }
+const char *nerf_last_error(const nerf_ctx *ctx) { return ctx ? ctx->err.c_str() : nerfhost::last_error_noctx(); }
 
 int nerf_create(int device_id, nerf_ctx **out) try {
     if (!out) return fail(nullptr, NERF_ERR_INVALID, "out is NULL");
@@ -662,99 +662,18 @@ int nerf_load_network_tensors(nerf_ctx *c, int which, int n, const char *const *
     return upload_net(c, which, hn);
 } NERF_CATCH(c)
 
-static const char kBlobMagic[8] = {'N', 'R', 'F', 'M', 'I', '3', '5', '5'};
-
-int nerf_pack_network_dir(const char *dir, const char *blob_path) try {
-    if (!dir || !blob_path) return fail(nullptr, NERF_ERR_INVALID, "NULL argument");
-    std::map<std::string, Tensor> params;
-    std::string err;
-    int rc = read_tensor_dir(dir, params, err);
-    if (rc) return fail(nullptr, rc, err);
-    HostNet hn;
-    rc = assemble_net(params, hn, err);
-    if (rc) return fail(nullptr, rc, err);
-    std::vector<float> ws, sm;
-    pack_network(hn, ws, sm);
-    FILE *f = fopen(blob_path, "wb");
-    if (!f) return fail(nullptr, NERF_ERR_IO, std::string("cannot create ") + blob_path);
-    const uint32_t hdr[2] = {1u, (uint32_t)(ws.size() + sm.size())};
-    const bool ok = fwrite(kBlobMagic, 1, 8, f) == 8 && fwrite(hdr, 4, 2, f) == 2 &&
-                    fwrite(ws.data(), 4, ws.size(), f) == ws.size() && fwrite(sm.data(), 4, sm.size(), f) == sm.size();
-    fclose(f);
-    return ok ? NERF_OK : fail(nullptr, NERF_ERR_IO, std::string("short write ") + blob_path);
-} NERF_CATCH(nullptr)
-
 int nerf_load_network_blob(nerf_ctx *c, int which, const char *blob_path) try {
     if (!c) return fail(nullptr, NERF_ERR_INVALID, "ctx is NULL");
     if (which != NERF_NET_COARSE && which != NERF_NET_FINE) return fail(c, NERF_ERR_INVALID, "which must be NERF_NET_COARSE or NERF_NET_FINE");
     if (!blob_path) return fail(c, NERF_ERR_INVALID, "blob_path is NULL");
     DeviceGuard dg(c->device);
-    FILE *f = fopen(blob_path, "rb");
-    if (!f) return fail(c, NERF_ERR_IO, std::string("read blob: ") + blob_path);
-    char magic[8]; uint32_t hdr[2] = {0, 0};
-    const size_t nw = (size_t)nerfmlp::kChunksFull * nerfmlp::kChunkFloats, ns = nerfmlp::kSmallFloats;
-    std::vector<float> ws(nw), sm(ns);
-    const bool ok = fread(magic, 1, 8, f) == 8 && fread(hdr, 4, 2, f) == 2 && !memcmp(magic, kBlobMagic, 8) && hdr[0] == 1u &&
-                    hdr[1] == nw + ns && fread(ws.data(), 4, nw, f) == nw && fread(sm.data(), 4, ns, f) == ns && fgetc(f) == EOF;
-    fclose(f);
-    if (!ok) return fail(c, NERF_ERR_SHAPE, std::string("not a version-1 packed network blob for this build: ") + blob_path);
+    std::vector<float> ws, sm;
+    std::string err;
+    const int rrc = read_blob_file(blob_path, ws, sm, err);
+    if (rrc) return fail(c, rrc, err);
     const int rc = upload_packed(c, which, ws, sm);
     return rc ? rc : bf16_from_f32_stream(c, which, ws);
 } NERF_CATCH(c)
-
-int nerf_camera_from_pose(const float c2w[12], float ref_h, float ref_w, float focal, float near_, float far_, int width,
-                          int height, nerf_camera *out) try {
-    if (!c2w || !out) return fail(nullptr, NERF_ERR_INVALID, "NULL argument");
-    const float origin[3] = {c2w[3], c2w[7], c2w[11]};
-    const float forward[3] = {-c2w[2], -c2w[6], -c2w[10]};
-    const float up[3] = {c2w[1], c2w[5], c2w[9]};
-    const float hwf[3] = {ref_h, ref_w, focal};
-    camera_from_values(near_, far_, origin, forward, up, hwf, width, height, out);
-    return NERF_OK;
-} NERF_CATCH(nullptr)
-
-int nerf_check_network_dir(const char *dir) try {
-    if (!dir) return fail(nullptr, NERF_ERR_INVALID, "dir is NULL");
-    std::map<std::string, Tensor> params;
-    std::string err;
-    int rc = read_tensor_dir(dir, params, err);
-    if (rc) return fail(nullptr, rc, err);
-    HostNet hn;
-    rc = assemble_net(params, hn, err);
-    if (rc) return fail(nullptr, rc, err);
-    return NERF_OK;
-} NERF_CATCH(nullptr)
-
-int nerf_debug_split_bf16x3(const float *values, size_t n, uint16_t *parts) try {
-    if ((!values || !parts) && n) return fail(nullptr, NERF_ERR_INVALID, "NULL argument");
-    for (size_t i = 0; i < n; ++i) split_bf16x3(values[i], parts + 3 * i);
-    return NERF_OK;
-} NERF_CATCH(nullptr)
-
-int nerf_debug_split_f16x2(const float *values, size_t n, uint16_t *parts) try {
-    if ((!values || !parts) && n) return fail(nullptr, NERF_ERR_INVALID, "NULL argument");
-    for (size_t i = 0; i < n; ++i) split_f16x2(values[i], parts + 2 * i);
-    return NERF_OK;
-} NERF_CATCH(nullptr)
-
-int nerf_debug_pack_network_dir(const char *dir, float *wstream, size_t wstream_cap, float *small, size_t small_cap,
-                                size_t *wstream_len, size_t *small_len) try {
-    if (!dir) return fail(nullptr, NERF_ERR_INVALID, "dir is NULL");
-    std::map<std::string, Tensor> params;
-    std::string err;
-    int rc = read_tensor_dir(dir, params, err);
-    if (rc) return fail(nullptr, rc, err);
-    HostNet hn;
-    rc = assemble_net(params, hn, err);
-    if (rc) return fail(nullptr, rc, err);
-    std::vector<float> ws, sm;
-    pack_network(hn, ws, sm);
-    if (wstream_len) *wstream_len = ws.size();
-    if (small_len) *small_len = sm.size();
-    if (wstream) { if (wstream_cap < ws.size()) return fail(nullptr, NERF_ERR_INVALID, "wstream buffer too small"); memcpy(wstream, ws.data(), ws.size() * sizeof(float)); }
-    if (small) { if (small_cap < sm.size()) return fail(nullptr, NERF_ERR_INVALID, "small buffer too small"); memcpy(small, sm.data(), sm.size() * sizeof(float)); }
-    return NERF_OK;
-} NERF_CATCH(nullptr)
 
 static int forward_device(nerf_ctx *c, int which, int dtype, const float *d_pts, const float *d_dirs, size_t n, float *d_rgb,
                           float *d_sigma, void *stream);
@@ -868,36 +787,6 @@ int nerf_debug_shader_clock_mhz(nerf_ctx *c, double *mhz) try {
     *mhz = f[f.size() / 2];
     return NERF_OK;
 } NERF_CATCH(c)
-
-int nerf_camera_from_json(const char *path, int width, int height, nerf_camera *out) try {
-    if (!path || !out) return fail(nullptr, NERF_ERR_INVALID, "NULL argument");
-    std::string err;
-    const int rc = camera_from_json(path, width, height, out, err);
-    return rc ? fail(nullptr, rc, err) : NERF_OK;
-} NERF_CATCH(nullptr)
-
-int nerf_camera_from_values(float near_, float far_, const float origin[3], const float forward[3], const float up[3],
-                            const float hwf[3], int width, int height, nerf_camera *out) try {
-    if (!origin || !forward || !up || !hwf || !out) return fail(nullptr, NERF_ERR_INVALID, "NULL argument");
-    camera_from_values(near_, far_, origin, forward, up, hwf, width, height, out);
-    return NERF_OK;
-} NERF_CATCH(nullptr)
-
-int nerf_save_ppm(const char *path, int width, int height, const float *rgb) try {
-    if (!path || !rgb) return fail(nullptr, NERF_ERR_INVALID, "NULL argument");
-    std::string err;
-    const int rc = save_ppm(path, width, height, rgb, err);
-    return rc ? fail(nullptr, rc, err) : NERF_OK;
-} NERF_CATCH(nullptr)
-
-void nerf_quantize_rgb8(const float *rgb, size_t n_pixels, uint8_t *out) { quantize_rgb8(rgb, n_pixels, out); }
-
-void nerf_quantize_rgba8(const float *rgb, size_t n_pixels, uint8_t *out) {
-    for (size_t i = 0; i < n_pixels; ++i) { // no allocation: nothing here can throw across the ABI
-        quantize_rgb8(rgb + 3 * i, 1, out + 4 * i);
-        out[4 * i + 3] = 255;
-    }
-}
 
 // ---- stage entry points ------------------------------------------------------------------------------------
 static int stage_rect(nerf_ctx *c, const nerf_camera *cam, int x0, int y0, int w, int h, RayGenArgs &g) {

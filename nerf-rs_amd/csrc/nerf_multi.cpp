@@ -7,7 +7,8 @@
 //   HOST  every band goes device -> host straight into its rows of the caller's buffer (no GPU-to-GPU traffic);
 //   PEER  bands are copied GPU -> GPU over xGMI (hipMemcpyPeerAsync) into a frame on ctxs[0]'s device, one D2H from there;
 //   RCCL  one ncclAllGather of the bands over xGMI leaves the whole frame on EVERY device (the north-star's "RCCL gather
-//         of the final framebuffer"); librccl is dlopen'ed on first use, so single-GPU hosts do not depend on it.
+//         of the final framebuffer"); librccl is dlopen'ed on first use, so single-GPU hosts do not depend on it.  Contexts that
+//         share a device (test boxes) rehearse the same slot layout with device-to-device copies instead of the collective.
 // The per-pixel counter RNG makes a band bit-identical to the same rows of a single-context frame.
 #include <dlfcn.h>
 #include <rccl/rccl.h>
@@ -125,23 +126,28 @@ int nerf_render_image_multi(nerf_ctx *const *ctxs, int n, const nerf_camera *cam
     band_of(ch, 0, n, &tmp, &max_rows);
     const size_t slot_floats = row_floats * max_rows; // RCCL: equal-sized slots, the ragged tail of a slot is unused
 
+    // RCCL refuses two ranks on one device.  When contexts SHARE a device (single-GPU test boxes) the collective step of the RCCL
+    // path is rehearsed as device-to-device copies into the same equal-slot buffers, so the slot layout, the stream ordering and the
+    // ragged compaction below are exercised; RCCL proper runs whenever the devices are distinct.
     std::vector<ncclComm_t> comms;
+    bool loopback = false;
     if (gather == NERF_GATHER_RCCL) {
         std::vector<int> devs;
         for (int i = 0; i < n; ++i) devs.push_back(ctxs[i]->device);
-        if (std::set<int>(devs.begin(), devs.end()).size() != devs.size())
-            return fail(c0, NERF_ERR_INVALID, "NERF_GATHER_RCCL needs one context per distinct device (RCCL refuses two ranks on one GPU); use NERF_GATHER_PEER or NERF_GATHER_HOST");
-        std::lock_guard<std::mutex> lk(g_rccl_mu);
-        std::string err;
-        if (!rccl_load(err)) return fail(c0, NERF_ERR_STATE, err);
-        auto it = g_rccl.comms.find(devs);
-        if (it == g_rccl.comms.end()) {
-            std::vector<ncclComm_t> cm(n, nullptr);
-            const ncclResult_t r = g_rccl.CommInitAll(cm.data(), n, devs.data());
-            if (r != ncclSuccess) return fail(c0, NERF_ERR_HIP, std::string("ncclCommInitAll: ") + g_rccl.GetErrorString(r));
-            it = g_rccl.comms.emplace(devs, cm).first;
+        loopback = std::set<int>(devs.begin(), devs.end()).size() != devs.size();
+        if (!loopback) {
+            std::lock_guard<std::mutex> lk(g_rccl_mu);
+            std::string err;
+            if (!rccl_load(err)) return fail(c0, NERF_ERR_STATE, err);
+            auto it = g_rccl.comms.find(devs);
+            if (it == g_rccl.comms.end()) {
+                std::vector<ncclComm_t> cm(n, nullptr);
+                const ncclResult_t r = g_rccl.CommInitAll(cm.data(), n, devs.data());
+                if (r != ncclSuccess) return fail(c0, NERF_ERR_HIP, std::string("ncclCommInitAll: ") + g_rccl.GetErrorString(r));
+                it = g_rccl.comms.emplace(devs, cm).first;
+            }
+            comms = it->second;
         }
-        comms = it->second;
     }
 
     // Destination buffers.  HOST: each context's d_out holds its band.  PEER: ctxs[0]'s d_out holds the frame (its own band is
@@ -216,31 +222,77 @@ int nerf_render_image_multi(nerf_ctx *const *ctxs, int n, const nerf_camera *cam
         for (int i = 0; i < n; ++i) pool.th.emplace_back(work, i);
     }
     for (int i = 0; i < n; ++i)
-        if (jobs[i].rc) { if (ctxs[i] != c0) c0->err = ctxs[i]->err; return fail(c0, jobs[i].rc, c0->err); }
+        if (jobs[i].rc) {
+            if (gather == NERF_GATHER_RCCL) // the other bands' kernels are still in flight (that path synchronises after the collective)
+                for (int k = 0; k < n; ++k) { DeviceGuard dg(ctxs[k]->device); (void)hipStreamSynchronize(ctxs[k]->stream); }
+            if (ctxs[i] != c0) c0->err = ctxs[i]->err;
+            return fail(c0, jobs[i].rc, c0->err);
+        }
 
     if (gather == NERF_GATHER_RCCL) {
         // ONE collective: every rank contributes its slot, every device receives all slots (in place).  The renders above are
         // already enqueued on the same streams, so stream order is the only synchronisation needed.
-        ncclResult_t r = g_rccl.GroupStart();
-        for (int i = 0; i < n && r == ncclSuccess; ++i)
-            r = g_rccl.AllGather(jobs[i].d_band, ctxs[i]->d_out, slot_floats, ncclFloat, comms[i], ctxs[i]->stream);
-        const ncclResult_t r2 = g_rccl.GroupEnd();
-        if (r == ncclSuccess) r = r2;
-        if (r != ncclSuccess) return fail(c0, NERF_ERR_HIP, std::string("ncclAllGather: ") + g_rccl.GetErrorString(r));
+        // From here on every context's stream carries work that reads other contexts' buffers: whatever fails, ALL streams are
+        // synchronised before this function returns (first error wins).
+        int rc_first = NERF_OK;
+        std::string err_first;
+        auto note = [&](hipError_t e, const char *what) {
+            if (e != hipSuccess && rc_first == NERF_OK) { rc_first = NERF_ERR_HIP; err_first = std::string(what) + ": " + hipGetErrorString(e); }
+            return e == hipSuccess;
+        };
+        std::vector<hipEvent_t> rendered;
+        if (loopback) {
+            // the same data movement as the in-place all-gather: slot k of context k -> slot k of every other context
+            rendered.assign(n, nullptr);
+            for (int i = 0; i < n; ++i) {
+                DeviceGuard dg(ctxs[i]->device);
+                if (note(hipEventCreateWithFlags(&rendered[i], hipEventDisableTiming), "hipEventCreate")) note(hipEventRecord(rendered[i], ctxs[i]->stream), "hipEventRecord");
+            }
+            for (int i = 0; i < n && rc_first == NERF_OK; ++i) {
+                nerf_ctx *c = ctxs[i];
+                DeviceGuard dg(c->device);
+                for (int k = 0; k < n && rc_first == NERF_OK; ++k) {
+                    if (k == i) continue;
+                    if (!note(hipStreamWaitEvent(c->stream, rendered[k], 0), "hipStreamWaitEvent")) break;
+                    const float *src = ctxs[k]->d_out + slot_floats * k;
+                    float *dst = c->d_out + slot_floats * k;
+                    note(ctxs[k]->device == c->device
+                             ? hipMemcpyAsync(dst, src, slot_floats * sizeof(float), hipMemcpyDeviceToDevice, c->stream)
+                             : hipMemcpyPeerAsync(dst, c->device, src, ctxs[k]->device, slot_floats * sizeof(float), c->stream),
+                         "all-gather rehearsal copy");
+                }
+            }
+        } else {
+            ncclResult_t r = g_rccl.GroupStart();
+            for (int i = 0; i < n && r == ncclSuccess; ++i)
+                r = g_rccl.AllGather(jobs[i].d_band, ctxs[i]->d_out, slot_floats, ncclFloat, comms[i], ctxs[i]->stream);
+            const ncclResult_t r2 = g_rccl.GroupEnd();
+            if (r == ncclSuccess) r = r2;
+            if (r != ncclSuccess) { rc_first = NERF_ERR_HIP; err_first = std::string("ncclAllGather: ") + g_rccl.GetErrorString(r); }
+        }
         for (int i = 0; i < n; ++i) {
             nerf_ctx *c = ctxs[i];
             DeviceGuard dg(c->device);
-            if (ragged) { // slots -> contiguous frame behind them (every device ends up with the whole frame)
+            if (ragged && rc_first == NERF_OK) { // slots -> contiguous frame behind them (every device ends up with the whole frame)
                 float *frame = c->d_out + slot_floats * n;
                 for (int k = 0; k < n; ++k)
                     if (jobs[k].band_floats)
-                        HIP_TRY(c, hipMemcpyAsync(frame + jobs[k].frame_off, c->d_out + slot_floats * k, jobs[k].band_floats * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+                        note(hipMemcpyAsync(frame + jobs[k].frame_off, c->d_out + slot_floats * k, jobs[k].band_floats * sizeof(float), hipMemcpyDeviceToDevice, c->stream), "slot compaction");
             }
-            if (i != 0) HIP_TRY(c, hipStreamSynchronize(c->stream));
         }
         d_frame0 = ragged ? c0->d_out + slot_floats * n : c0->d_out;
+        if (rc_first == NERF_OK) {
+            DeviceGuard dg(c0->device);
+            note(hipMemcpyAsync(rgb_out, d_frame0, frame_floats * sizeof(float), hipMemcpyDeviceToHost, c0->stream), "frame D2H");
+        }
+        for (int i = 0; i < n; ++i) { // every stream, on every path: a context's buffers are read by the other contexts' streams
+            DeviceGuard dg(ctxs[i]->device);
+            note(hipStreamSynchronize(ctxs[i]->stream), "hipStreamSynchronize");
+        }
+        for (hipEvent_t e : rendered) if (e) (void)hipEventDestroy(e);
+        return rc_first == NERF_OK ? NERF_OK : fail(c0, rc_first, err_first);
     }
-    if (gather != NERF_GATHER_HOST) {
+    if (gather == NERF_GATHER_PEER) {
         DeviceGuard dg(c0->device);
         HIP_TRY(c0, hipMemcpyAsync(rgb_out, d_frame0, frame_floats * sizeof(float), hipMemcpyDeviceToHost, c0->stream));
         HIP_TRY(c0, hipStreamSynchronize(c0->stream));

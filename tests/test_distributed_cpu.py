@@ -39,8 +39,11 @@ def _worker(rank, world, port, crop, out_dir):
         def band_renderer(c):
             return O.render_image(co, fi, ocam, O.make_opts(64, 128, crop=c, seed=0, threads=2))
 
-        frame = nerf_rs_amd.render_image_distributed(None, None, cam, 128, seed=0, crop=crop, band_renderer=band_renderer)
+        marks = []
+        frame = nerf_rs_amd.render_image_distributed(None, None, cam, 128, seed=0, crop=crop, band_renderer=band_renderer, timings=marks)
         np.save(os.path.join(out_dir, f"frame{rank}.npy"), frame)
+        (ms_render, ms_gather), = [m.ms() for m in marks]  # attribution marks: render vs gather (bench.py's N > 1 line)
+        assert ms_render > 0 and ms_gather > 0
     finally:
         dist.destroy_process_group()
 

@@ -346,6 +346,107 @@ def test_rust_sys_crate_declares_the_whole_header():
     assert integ_fns <= set(header) and {"nerf_create", "nerf_render_image", "nerf_render_image_multi", "nerf_forward_batch"} <= integ_fns
 
 
+# ---- C declaration -> Rust FFI type, for the textual ABI check below (no Rust compiler exists in this image) ----------------
+_C_SCALARS = {"int": "c_int", "int32_t": "i32", "uint32_t": "u32", "int64_t": "i64", "uint64_t": "u64", "uint16_t": "u16",
+              "uint8_t": "u8", "size_t": "usize", "float": "f32", "double": "f64", "char": "c_char", "void": "c_void",
+              "nerf_ctx": "nerf_ctx", "nerf_camera": "nerf_camera", "nerf_render_opts": "nerf_render_opts", "nerf_stats": "nerf_stats"}
+
+
+def _c_decl_to_rust(decl):
+    """`const float *const *data` -> ('data', '*const *const f32'); `float pos[3]` -> ('pos', '[f32; 3]') for struct fields and
+    ('pos', '*const f32' / '*mut f32') for parameters is handled by the caller through `array`."""
+    decl = decl.strip()
+    m = re.match(r"^(.*?)([A-Za-z_][A-Za-z_0-9]*)\s*(\[(\d+)\])?$", decl)
+    assert m, decl
+    ty, name, _, arr = m.group(1).strip(), m.group(2), m.group(3), m.group(4)
+    toks = re.findall(r"[A-Za-z_][A-Za-z_0-9]*|\*", ty)
+    # C reads right to left: base [const] then a list of ('*', const-after?)
+    base_const = False
+    base = None
+    ptrs = []
+    for t in toks:
+        if t == "const":
+            if ptrs:
+                ptrs[-1] = True          # `*const`: the pointer just seen is itself const
+            else:
+                base_const = True
+        elif t == "*":
+            ptrs.append(False)
+        else:
+            assert base is None, decl
+            base = t
+    rust = _C_SCALARS[base]
+    # innermost pointer takes its mutability from the pointee's constness, each outer one from the const-ness of the pointer it points to
+    pointee_const = base_const
+    for self_const in ptrs:
+        rust = ("*const " if pointee_const else "*mut ") + rust
+        pointee_const = self_const
+    return name, rust, (int(arr) if arr else None), base_const
+
+
+def _c_struct_fields(text, struct):
+    """[(name, rust type)] of `typedef struct { ... } struct;` in declaration order."""
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    body = re.search(r"typedef struct \{([^}]*)\}\s*" + struct + r"\s*;", text, flags=re.S).group(1)
+    out = []
+    for stmt in body.split(";"):
+        stmt = " ".join(stmt.split())
+        if not stmt:
+            continue
+        first, *rest = [x.strip() for x in stmt.split(",")]
+        name, rust, arr, _ = _c_decl_to_rust(first)
+        ty = first[:first.rindex(name)]
+        for decl in [first] + [ty + r for r in rest]:
+            name, rust, arr, _ = _c_decl_to_rust(decl)
+            out.append((name, f"[{rust}; {arr}]" if arr else rust))
+    return out
+
+
+def _c_param_types(text):
+    """function name -> [rust parameter types] for every prototype of the header."""
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    out = {}
+    for ret, name, args in re.findall(r"\b(int|void|const char \*)\s*(nerf_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", text, flags=re.S):
+        args = " ".join(args.split())
+        types = []
+        if args not in ("", "void"):
+            for a in args.split(","):
+                _, rust, arr, base_const = _c_decl_to_rust(a)
+                types.append((("*const " if base_const else "*mut ") + rust) if arr else rust)   # `const float c2w[12]` decays to a pointer
+        out[name] = (types, {"int": "c_int", "void": "", "const char *": "*const c_char"}[ret])
+    return out
+
+
+def test_rust_sys_crate_matches_the_header_types():
+    """The `-sys` crate will never meet a compiler here, so field ORDER and TYPES of the #[repr(C)] mirrors, and the type of every
+    argument and return value of the extern block, are derived from include/nerf_mi355x.h and compared textually (VERDICT r2 #8)."""
+    from nerf_rs_amd import _lib
+    htext = open(HEADER).read()
+    rs = re.sub(r"//.*", "", open(os.path.join(ROOT, "bindings", "rust", "nerf-mi355x-sys", "src", "lib.rs")).read())
+    ctypes_names = {C.c_int32: "i32", C.c_uint32: "u32", C.c_uint64: "u64", C.c_float: "f32", C.c_double: "f64", C.c_float * 3: "[f32; 3]"}
+    for struct, mirror in (("nerf_camera", _lib.CCamera), ("nerf_render_opts", _lib.COpts), ("nerf_stats", _lib.CStats)):
+        want = _c_struct_fields(htext, struct)
+        body = rs[rs.index(f"pub struct {struct} {{"):]
+        body = body[:body.index("}")]
+        got = [(n.rstrip("_"), " ".join(t.split())) for n, t in re.findall(r"pub ([a-z_0-9]+):\s*([^,\n]+),", body)]
+        assert got == [(n.rstrip("_"), t) for n, t in want], (struct, got, want)          # `near_` / `far_` are `near` / `far` in Rust
+        py = [(n.rstrip("_"), ctypes_names[t]) for n, t in mirror._fields_]
+        assert py == [(n.rstrip("_"), t) for n, t in want], (struct, py, want)             # and the ctypes mirror agrees as well
+    block = rs[rs.index('extern "C" {'):]
+    block = block[:block.index("\n}")]
+    want = _c_param_types(htext)
+    got = {}
+    for name, args, ret in re.findall(r"pub fn (nerf_[a-z0-9_]+)\s*\(([^)]*)\)\s*(->\s*[^;]+)?;", block, flags=re.S):
+        types = [" ".join(a.split(":", 1)[1].split()) for a in args.split(",") if a.strip()]
+        got[name] = (types, " ".join(ret.replace("->", "").split()) if ret else "")
+    assert set(got) == set(want)
+    for name in want:
+        assert got[name] == want[name], (name, got[name], want[name])
+    consts = dict(re.findall(r"pub const (NERF_[A-Z0-9_]+): (?:c_int|i32) = (-?\d+);", rs))
+    henum = dict(re.findall(r"\b(NERF_[A-Z0-9_]+)\s*=\s*(-?\d+)", re.sub(r"/\*.*?\*/", "", htext, flags=re.S)))
+    assert consts == henum, (sorted(set(henum) ^ set(consts)), {k: (consts.get(k), henum.get(k)) for k in henum if consts.get(k) != henum.get(k)})
+
+
 def test_struct_sizes_match_the_library(native):
     from nerf_rs_amd import _lib
     L = native.load_library()

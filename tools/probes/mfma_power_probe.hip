@@ -31,10 +31,12 @@ template <> struct Op<V_BF16_16> { using T = bf16x8; static constexpr bool k32 =
 template <> struct Op<V_F16_32> { using T = f16x8; static constexpr bool k32 = true; };
 template <> struct Op<V_F16_16> { using T = f16x8; static constexpr bool k32 = false; };
 
-__device__ __forceinline__ f32x16 mm32(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
-__device__ __forceinline__ f32x16 mm32(f16x8 a, f16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
-__device__ __forceinline__ f32x4 mm16(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
-__device__ __forceinline__ f32x4 mm16(f16x8 a, f16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+// Inline asm with the accumulators tied in place ("+v": VGPR-form accumulators): the builtin form let hipcc rotate the 16 small
+// accumulator tiles through AGPRs with ~100 v_accvgpr moves per iteration, which measured the moves, not the matrix pipe.
+__device__ __forceinline__ void mm32(bf16x8 a, bf16x8 b, f32x16 &c) { asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b)); }
+__device__ __forceinline__ void mm32(f16x8 a, f16x8 b, f32x16 &c) { asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b)); }
+__device__ __forceinline__ void mm16(bf16x8 a, bf16x8 b, f32x4 &c) { asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b)); }
+__device__ __forceinline__ void mm16(f16x8 a, f16x8 b, f32x4 &c) { asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b)); }
 
 // Output tile per wave is 64 x 64 in both shapes: 2 x 2 tiles of 32x32 (4 MFMAs of 32 768 FLOP) or 4 x 4 tiles of 16x16 (16 MFMAs of
 // 16 384 FLOP) per k-step: 131 072 / 262 144 FLOP per step.  NK k-steps of operands are held in registers and cycled through.
@@ -74,8 +76,8 @@ __global__ __launch_bounds__(256, 1) void probe(const u32x4 *src, float *sink, u
             for (int i = 0; i < NA; ++i)
 #pragma unroll
                 for (int j = 0; j < NA; ++j) {
-                    if constexpr (K32) c32[i][j] = mm32(av[i], b[k][j], c32[i][j]);
-                    else c16[i][j] = mm16(av[i], b[k][j], c16[i][j]);
+                    if constexpr (K32) mm32(av[i], b[k][j], c32[i][j]);
+                    else mm16(av[i], b[k][j], c16[i][j]);
                 }
         }
         // keep the accumulators bounded without leaving the matrix pipe idle for long: nothing (f32 does not overflow in this many steps
@@ -98,13 +100,21 @@ static uint16_t rnd16(uint32_t &st, bool bf) {
 }
 
 template <int V, bool LDSA>
-static void run(const char *name, int n_cus, double seconds, bool zeros) {
+static void run(const char *name, int n_cus, double seconds, int data) { // data: 0 random, 1 zeros, 2 = A random (weights), B like ReLU outputs (half of them 0, the rest positive)
+    const bool zeros = data == 1;
     constexpr bool K32 = Op<V>::k32;
     const bool bf = (V == V_BF16_32 || V == V_BF16_16);
     const size_t n_vec = (size_t)n_cus * 4 * 4 * 8 * 64;
     std::vector<uint16_t> h(n_vec * 8);
     uint32_t st = 12345u + V;
-    for (auto &x : h) x = zeros ? 0 : rnd16(st, bf);
+    for (size_t i = 0; i < h.size(); ++i) {
+        uint16_t x = zeros ? 0 : rnd16(st, bf);
+        if (data == 2 && ((i / 8 / 64) % 8) >= 4) { // a B fragment (src layout: [..][k][8 frags: 4 A then 4 B][64 lanes][8 values])
+            st = st * 1664525u + 1013904223u;
+            x = (st >> 30) & 1u ? (uint16_t)(x & 0x7fffu) : (uint16_t)0;
+        }
+        h[i] = x;
+    }
     u32x4 *d_src; float *d_sink; unsigned long long *d_st;
     CK(hipMalloc((void **)&d_src, n_vec * 16)); CK(hipMalloc((void **)&d_sink, (size_t)n_cus * 256 * 4)); CK(hipMalloc((void **)&d_st, (size_t)n_cus * 16));
     CK(hipMemcpy(d_src, h.data(), n_vec * 16, hipMemcpyHostToDevice));
@@ -130,7 +140,7 @@ static void run(const char *name, int n_cus, double seconds, bool zeros) {
     const double tf = flop * reps / (ms * 1e-3) / 1e12;
     const double cyc_per_step = mhz.empty() ? 0 : (ms * 1e-3 / reps) * mhz[mhz.size() / 2] * 1e6 / ((double)iters * 4);
     printf("{\"variant\": \"%s\", \"data\": \"%s\", \"tflops\": %.1f, \"frac_of_2500\": %.3f, \"clock_mhz_median\": %.0f, \"cycles_per_kstep\": %.1f, \"ms_per_launch\": %.2f, \"launches\": %d}\n",
-           name, zeros ? "zeros" : "random", tf, tf / 2500.0, mhz.empty() ? 0.0 : mhz[mhz.size() / 2], cyc_per_step, ms / reps, reps);
+           name, zeros ? "zeros" : data == 2 ? "A random, B relu-like (half zeros, positive)" : "random", tf, tf / 2500.0, mhz.empty() ? 0.0 : mhz[mhz.size() / 2], cyc_per_step, ms / reps, reps);
     fflush(stdout);
     CK(hipFree(d_src)); CK(hipFree(d_sink)); CK(hipFree(d_st));
 }
@@ -140,15 +150,19 @@ int main(int argc, char **argv) {
     hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0));
     const int n_cus = prop.multiProcessorCount;
     printf("{\"device\": \"%s\", \"cus\": %d}\n", prop.gcnArchName, n_cus);
-    run<V_BF16_32, false>("bf16 32x32x16 regs", n_cus, seconds, false);
-    run<V_BF16_16, false>("bf16 16x16x32 regs", n_cus, seconds, false);
-    run<V_F16_32, false>("f16 32x32x16 regs", n_cus, seconds, false);
-    run<V_F16_16, false>("f16 16x16x32 regs", n_cus, seconds, false);
-    run<V_BF16_32, true>("bf16 32x32x16 A from LDS", n_cus, seconds, false);
-    run<V_BF16_16, true>("bf16 16x16x32 A from LDS", n_cus, seconds, false);
-    run<V_F16_32, true>("f16 32x32x16 A from LDS", n_cus, seconds, false);
-    run<V_F16_16, true>("f16 16x16x32 A from LDS", n_cus, seconds, false);
-    run<V_BF16_32, false>("bf16 32x32x16 regs", n_cus, seconds, true);
-    run<V_BF16_16, false>("bf16 16x16x32 regs", n_cus, seconds, true);
+    run<V_BF16_32, false>("bf16 32x32x16 regs", n_cus, seconds, 0);
+    run<V_BF16_16, false>("bf16 16x16x32 regs", n_cus, seconds, 0);
+    run<V_F16_32, false>("f16 32x32x16 regs", n_cus, seconds, 0);
+    run<V_F16_16, false>("f16 16x16x32 regs", n_cus, seconds, 0);
+    run<V_BF16_32, true>("bf16 32x32x16 A from LDS", n_cus, seconds, 0);
+    run<V_BF16_16, true>("bf16 16x16x32 A from LDS", n_cus, seconds, 0);
+    run<V_F16_32, true>("f16 32x32x16 A from LDS", n_cus, seconds, 0);
+    run<V_F16_16, true>("f16 16x16x32 A from LDS", n_cus, seconds, 0);
+    run<V_BF16_32, true>("bf16 32x32x16 A from LDS", n_cus, seconds, 2);
+    run<V_BF16_16, true>("bf16 16x16x32 A from LDS", n_cus, seconds, 2);
+    run<V_F16_32, true>("f16 32x32x16 A from LDS", n_cus, seconds, 2);
+    run<V_F16_16, true>("f16 16x16x32 A from LDS", n_cus, seconds, 2);
+    run<V_BF16_32, false>("bf16 32x32x16 regs", n_cus, seconds, 1);
+    run<V_BF16_16, false>("bf16 16x16x32 regs", n_cus, seconds, 1);
     return 0;
 }
