@@ -135,6 +135,9 @@ extern "C" {
     pub fn nerf_stage_resample(ctx: *mut nerf_ctx, n_rays: usize, nc: c_int, nf: c_int, far: f32, seed: u64,
                                pixel_index: *const u32, t_coarse: *const f32, sigma_coarse: *const f32, u: *const f32,
                                w_out: *mut f32, cdf_out: *mut f32, t_new_out: *mut f32, t_fine_out: *mut f32) -> c_int;
+    pub fn nerf_stage_hybrid_flags(ctx: *mut nerf_ctx, n_rays: usize, nc: c_int, nf: c_int, far: f32, seed: u64,
+                                   pixel_index: *const u32, t_coarse: *const f32, sigma_coarse: *const f32, u: *const f32,
+                                   tau: f32, flags_out: *mut u8, t_new_out: *mut f32) -> c_int;
     pub fn nerf_stage_integrate(ctx: *mut nerf_ctx, n_rays: usize, n: c_int, far: f32, rgb_aos: *const f32,
                                 sigma: *const f32, t: *const f32, rgb_out: *mut f32, w_out: *mut f32) -> c_int;
 }

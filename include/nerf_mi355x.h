@@ -236,6 +236,13 @@ int nerf_stage_stratified(nerf_ctx *ctx, const nerf_camera *cam, int x0, int y0,
 int nerf_stage_resample(nerf_ctx *ctx, size_t n_rays, int nc, int nf, float far_, uint64_t seed,
                         const uint32_t *pixel_index, const float *t_coarse, const float *sigma_coarse, const float *u,
                         float *w_out, float *cdf_out, float *t_new_out, float *t_fine_out);
+/* hybrid_sampling's per-ray decision (nerf_render_opts.hybrid_sampling), exposed so that its promise can be tested directly: the same
+ * kernel, inputs and RNG as nerf_stage_resample; flags_out[r] = 1 iff ray r would be redone in f32 (a draw predicted to move by more
+ * than tau in t under the split arithmetics' density error, or a transmittance within 0.1 % of the cut).  tau = 0 selects the
+ * context's threshold (1e-5).  t_new_out (n_rays x nf, the unsorted draws) optional. */
+int nerf_stage_hybrid_flags(nerf_ctx *ctx, size_t n_rays, int nc, int nf, float far_, uint64_t seed,
+                            const uint32_t *pixel_index, const float *t_coarse, const float *sigma_coarse, const float *u,
+                            float tau, uint8_t *flags_out, float *t_new_out);
 /* integrate_ray (src/lib.rs:176-195); w_out (n_rays x n) optional */
 int nerf_stage_integrate(nerf_ctx *ctx, size_t n_rays, int n, float far_, const float *rgb_aos, const float *sigma,
                          const float *t, float *rgb_out, float *w_out);

@@ -85,6 +85,8 @@ PROTOTYPES = {
                                         C.c_uint64, f32p]),
     "nerf_stage_resample": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_float, C.c_uint64, u32p, f32p, f32p,
                                       f32p, f32p, f32p, f32p, f32p]),
+    "nerf_stage_hybrid_flags": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_float, C.c_uint64, u32p, f32p, f32p, f32p,
+                                          C.c_float, C.POINTER(C.c_uint8), f32p]),
     "nerf_stage_integrate": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.c_float, f32p, f32p, f32p, f32p, f32p]),
 }
 

@@ -108,6 +108,18 @@ class Renderer:
                                           None if uu is None else _p(uu), _p(w), _p(cdf), _p(tn), _p(tf)), self.handle)
         return {"w": w, "cdf": cdf, "t_new": tn, "t_fine": tf}
 
+    def stage_hybrid_flags(self, t_coarse, sigma_coarse, nf, far, seed=0, pixel_index=None, u=None, tau=0.0):
+        """hybrid_sampling's per-ray decision for the given coarse densities -> (flags (R,) bool, t_new (R, nf) unsorted draws)."""
+        t = _f32(t_coarse); s = _f32(sigma_coarse)
+        R, nc = t.shape
+        flags = np.zeros(R, np.uint8); tn = np.empty((R, nf), np.float32)
+        pix = None if pixel_index is None else np.ascontiguousarray(pixel_index, dtype=np.uint32)
+        uu = None if u is None else _f32(u)
+        check(self._L.nerf_stage_hybrid_flags(self.handle, R, nc, nf, far, seed, None if pix is None else pix.ctypes.data_as(u32p),
+                                              _p(t), _p(s), None if uu is None else _p(uu), tau,
+                                              flags.ctypes.data_as(C.POINTER(C.c_uint8)), _p(tn)), self.handle)
+        return flags.astype(bool), tn
+
     def stage_integrate(self, rgb, sigma, t, far):
         c = _f32(rgb); s = _f32(sigma); t = _f32(t)
         R, n = t.shape

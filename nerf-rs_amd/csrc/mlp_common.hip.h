@@ -143,28 +143,31 @@ __device__ __forceinline__ void encode_dir_doubling(float dx, float dy, float dz
 
 __device__ __forceinline__ float xhalf_sum(float v) { return v + __shfl_xor(v, 32, 64); }
 
-// rgb head on the VALU + sigmoid (src/network.rs:223, :165) from the four f32 accumulator tiles of the viewdirs layer.
+// rgb head on the VALU + sigmoid (src/network.rs:223, :165) from the four f32 accumulator tiles of the viewdirs layer: one channel.
+template <class Tiles>
+__device__ __forceinline__ float rgb_channel(const Tiles &V, const LDS_AS float *small, int h, int ch) {
+    using namespace nerfmlp;
+    const LDS_AS f32x4 *w = (const LDS_AS f32x4 *)(small + kRgbWOff + (h * 3 + ch) * 64);
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 wv = w[t * 4 + q];
+            a0 = fmaf(wv[0], relu(V[t][4 * q + 0]), a0);
+            a1 = fmaf(wv[1], relu(V[t][4 * q + 1]), a1);
+            a2 = fmaf(wv[2], relu(V[t][4 * q + 2]), a2);
+            a3 = fmaf(wv[3], relu(V[t][4 * q + 3]), a3);
+        }
+    }
+    const float v = xhalf_sum((a0 + a1) + (a2 + a3)) + small[kMiscOff + 1 + ch];
+    return 1.0f / (1.0f + expf(-v));
+}
+
 template <class Tiles>
 __device__ __forceinline__ void rgb_head(const Tiles &V, const LDS_AS float *small, int h, float (&c)[3]) {
-    using namespace nerfmlp;
 #pragma unroll
-    for (int ch = 0; ch < 3; ++ch) {
-        const LDS_AS f32x4 *w = (const LDS_AS f32x4 *)(small + kRgbWOff + (h * 3 + ch) * 64);
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const f32x4 wv = w[t * 4 + q];
-                a0 = fmaf(wv[0], relu(V[t][4 * q + 0]), a0);
-                a1 = fmaf(wv[1], relu(V[t][4 * q + 1]), a1);
-                a2 = fmaf(wv[2], relu(V[t][4 * q + 2]), a2);
-                a3 = fmaf(wv[3], relu(V[t][4 * q + 3]), a3);
-            }
-        }
-        const float v = xhalf_sum((a0 + a1) + (a2 + a3)) + small[kMiscOff + 1 + ch];
-        c[ch] = 1.0f / (1.0f + expf(-v));
-    }
+    for (int ch = 0; ch < 3; ++ch) c[ch] = rgb_channel(V, small, h, ch);
 }
 
 // Raw per-point inputs: 6 floats.  MODE_POINTS: position + direction as given (src/network.rs:197).  MODE_RAYS:

@@ -36,11 +36,13 @@ hipError_t nerf_mlp_bf16v2_launch(const MlpArgs &a, bool full, int n_blocks, hip
 hipError_t nerf_mlp_bf16x3_init();
 hipError_t nerf_mlp_bf16x3_launch(const MlpArgs &a, bool full, int n_blocks, hipStream_t stream);
 
-// ---- exact dead-sample skipping (mlp_kernel_seq.hip; f32 only) -------------------------------------------------------
+// ---- exact dead-sample skipping (mlp_kernel_seq.hip for f32; mlp_split_kernels.hip.h for the split arithmetics) ------------
 // Ray-sequential trunk: waves take rays from a device-side queue and walk each ray's samples front to back in chunks of 32,
 // stopping at the reference's T < 1e-4 cut (src/lib.rs:276-279).  sigma_out must be zero-filled by the caller (samples behind
-// the cut are never written).  With export_live the trunk output of every sample with weight > 0 goes to `h8` (compacted,
-// 1 KiB per sample; capacity = all samples of the launch, nerf_seq_h8_bytes) for nerf_colour_launch.
+// the cut are never written).  With export_live the colour head runs on every sample with weight > 0:
+//   f32 kernel            in the same launch (live samples compacted in LDS, colour passes of 32 columns): set rgb_out (zero-filled);
+//   split arithmetics     trunk output to `h8` (compacted in HBM, 1 KiB per sample; capacity = all samples of the launch,
+//                         nerf_seq_h8_bytes) for the second launch nerf_colour_*_launch.
 struct SeqArgs {
     const float *wstream;      // the f32 packed weight stream (sigma part is used)
     const float *small_params;
@@ -51,10 +53,11 @@ struct SeqArgs {
     float far_;
     float *sigma_out;          // n_rays x samples_per_ray
     unsigned int *ray_counter; // zeroed before the launch
-    unsigned int *live_count;  // zeroed before the launch (export_live)
+    unsigned int *live_count;  // zeroed before the launch (export_live): number of samples with weight > 0
+    float *rgb_out;            // f32 kernel with export_live: n_rays x samples_per_ray x 3, zero-filled by the caller
     float *h8;
     unsigned int *slot_point;  // sample index (ray * samples_per_ray + k) of every exported slot
-    unsigned long long *stats; // optional: += number of 32-sample chunks evaluated
+    unsigned long long *stats; // optional: += number of samples evaluated
     // hybrid sampling: evaluate only the rays of a device-side list (n_rays then only bounds the grid); retired rays zero-fill the
     // rest of their sigma row themselves (the row holds another arithmetic's values, the caller does not clear it)
     const unsigned int *ray_list;
@@ -74,7 +77,6 @@ struct ColourArgs {
 hipError_t nerf_seq_init();
 size_t nerf_seq_h8_bytes(size_t n_samples);
 hipError_t nerf_trunk_seq_launch(const SeqArgs &a, bool export_live, int n_blocks, hipStream_t stream);
-hipError_t nerf_colour_launch(const ColourArgs &a, int n_blocks, hipStream_t stream);
 // the same two kernels in the bf16x3 arithmetic (mlp_kernel_bf16x3.hip): a.wstream is the three-part stream; the h8 tiles and
 // the small parameters have the f32 kernels' layout
 hipError_t nerf_seq_x3_init();

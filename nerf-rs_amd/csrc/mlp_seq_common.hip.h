@@ -20,15 +20,17 @@ constexpr int kH8TileFloats = 32 * 64 * 4; // one 32-sample export tile: [t * 4 
 // What a wave is working on (wave-uniform): one ray at a time, its chunks of 32 samples front to back.
 struct RayWork {
     int ray, chunk, n_chunks;
-    float T;                        // transmittance in front of the current chunk
-    unsigned long long chunks_done; // statistics: chunks this wave evaluated
+    float T;                         // transmittance in front of the current chunk
+    unsigned long long samples_done; // statistics: samples this wave evaluated (a ray's last chunk may be partial)
+    unsigned long long live_done;    // statistics: samples with weight > 0 this wave found (in-kernel colour passes only)
 };
 
 __device__ __forceinline__ void work_init(RayWork &W, const SeqArgs &A) {
     W.n_chunks = (A.samples_per_ray + 31) >> 5;
     W.ray = A.n_rays; W.chunk = W.n_chunks; // no ray yet
     W.T = 1.0f;
-    W.chunks_done = 0;
+    W.samples_done = 0;
+    W.live_done = 0;
 }
 
 // Take the next ray from the device-side queue if the current one is finished, then vote: the four waves of a workgroup walk the
@@ -79,11 +81,16 @@ __device__ __forceinline__ float lane_value(float v, int k) {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), k));
 }
 
-// After the trunk: store sigma, continue the transmittance recurrence through the chunk, export the trunk outputs `Y` (eight
-// accumulator tiles in the C/D layout of the 32x32 MFMAs) of the samples with weight > 0, and advance to the next chunk -- or
-// retire the ray at the cut (A): behind it nothing of this ray is evaluated.
-template <bool EXPORT, class Tiles>
-__device__ __forceinline__ void chunk_finish(RayWork &W, const SeqArgs &A, const ChunkIn &c, float sigma, const Tiles &Y, int lane, int p, int h) {
+// After the trunk, part 1: store sigma and continue the transmittance recurrence through the chunk.  Returns which samples are LIVE
+// (weight > 0: exactly the samples whose colour reaches the pixel (B)) and whether the ray is cut inside this chunk (A).
+struct LiveInfo {
+    bool live;               // this lane's sample (both lane-halves of a column agree)
+    unsigned long long mask; // live columns (bit p)
+    int n_live;
+    bool cut;
+};
+
+__device__ __forceinline__ LiveInfo chunk_scan(RayWork &W, const SeqArgs &A, const ChunkIn &c, float sigma, int p, int h) {
     const int M = A.samples_per_ray;
     if (c.valid && h == 0) A.sigma_out[c.base + c.s] = sigma;
     float delta = (c.s + 1 < M) ? c.t_next - c.t : A.far_ - c.t;
@@ -100,17 +107,36 @@ __device__ __forceinline__ void chunk_finish(RayWork &W, const SeqArgs &A, const
         cut = cut || T < 1e-4f;
     }
     W.T = T;
-    if (c.has) ++W.chunks_done;
+    if (c.has) { const int left = M - 32 * W.chunk; W.samples_done += (unsigned)(left < 32 ? left : 32); }
+    LiveInfo li;
+    li.live = my_w > 0.0f;
+    li.mask = __ballot(li.live) & 0xffffffffull;
+    li.n_live = __popcll(li.mask);
+    li.cut = cut;
+    return li;
+}
+
+// Part 2: advance to the next chunk -- or retire the ray at the cut (A): behind it nothing of this ray is evaluated.
+__device__ __forceinline__ void chunk_advance(RayWork &W, const SeqArgs &A, const ChunkIn &c, bool cut, int p, int h) {
+    const int M = A.samples_per_ray;
+    if (A.zero_fill_after_cut && cut && c.has && h == 0)
+        for (int cc = W.chunk + 1; cc < W.n_chunks; ++cc)
+            if (cc * 32 + p < M) A.sigma_out[c.base + cc * 32 + p] = 0.0f;
+    W.chunk = (cut || !c.has) ? W.n_chunks : W.chunk + 1;
+}
+
+// The two-launch form (split arithmetics): export the trunk outputs `Y` (eight accumulator tiles in the C/D layout of the 32x32
+// MFMAs) of the live samples to the compacted HBM buffer of the colour kernel.
+template <bool EXPORT, class Tiles>
+__device__ __forceinline__ void chunk_finish(RayWork &W, const SeqArgs &A, const ChunkIn &c, float sigma, const Tiles &Y, int lane, int p, int h) {
+    const LiveInfo li = chunk_scan(W, A, c, sigma, p, h);
     if (EXPORT) {
-        const bool live = my_w > 0.0f; // exactly the samples whose colour reaches the pixel (B)
-        const unsigned long long m = __ballot(live) & 0xffffffffull;
-        const int n_live = __popcll(m);
-        if (n_live) {
+        if (li.n_live) {
             unsigned b = 0;
-            if (lane == 0) b = atomicAdd(A.live_count, (unsigned)n_live);
+            if (lane == 0) b = atomicAdd(A.live_count, (unsigned)li.n_live);
             b = (unsigned)__builtin_amdgcn_readfirstlane((int)b);
-            if (live) {
-                const unsigned slot = b + (unsigned)__popcll(m & ((1ull << p) - 1ull));
+            if (li.live) {
+                const unsigned slot = b + (unsigned)__popcll(li.mask & ((1ull << p) - 1ull));
                 float *dst = A.h8 + (size_t)(slot >> 5) * kH8TileFloats + ((slot & 31) + 32 * h) * 4;
 #pragma unroll
                 for (int tt = 0; tt < 8; ++tt)
@@ -124,14 +150,12 @@ __device__ __forceinline__ void chunk_finish(RayWork &W, const SeqArgs &A, const
             }
         }
     }
-    if (A.zero_fill_after_cut && cut && c.has && h == 0)
-        for (int cc = W.chunk + 1; cc < W.n_chunks; ++cc)
-            if (cc * 32 + p < M) A.sigma_out[c.base + cc * 32 + p] = 0.0f;
-    W.chunk = (cut || !c.has) ? W.n_chunks : W.chunk + 1;
+    chunk_advance(W, A, c, li.cut, p, h);
 }
 
 __device__ __forceinline__ void work_done(const RayWork &W, const SeqArgs &A, int lane) {
-    if (A.stats && lane == 0 && W.chunks_done) atomicAdd(A.stats, W.chunks_done);
+    if (A.stats && lane == 0 && W.samples_done) atomicAdd(A.stats, W.samples_done);
+    if (A.live_count && lane == 0 && W.live_done) atomicAdd(A.live_count, (unsigned)W.live_done); // in-kernel colour passes: a statistic only
 }
 
 // ---- colour kernel side: one compacted slot per MFMA column ------------------------------------------------------------

@@ -290,8 +290,10 @@ int nerfint::render_device(nerf_ctx *c, const nerf_camera *cam, const nerf_rende
     const int RW = cw * s, RH = ch * s, RX0 = x0 * s, RY0 = y0 * s;
     // a pass must keep rays * samples within int32 (kernel indices) as well as within the configured budget
     size_t pass_cap = std::min<size_t>(c->max_rays_per_pass, (size_t)0x3fffffff / (size_t)M);
-    // skip_dead: the compacted trunk outputs are sized for the worst case (every sample of a pass live, 1 KiB each)
-    if (seq) {
+    // skip_dead in a split arithmetic (two launches): the compacted trunk outputs are sized for the worst case (every sample of a pass
+    // live, 1 KiB each).  The f32 kernel compacts in LDS and runs its colour passes in the same launch: no buffer, no extra passes.
+    const bool h8_export = seq && split_dtype(dtype);
+    if (h8_export) {
         size_t budget = c->max_export_bytes, free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) // never more than half of what the device can still give (plus what we already hold)
             budget = std::min(budget, (free_b + c->h8_bytes) / 2);
@@ -306,7 +308,7 @@ int nerfint::render_device(nerf_ctx *c, const nerf_camera *cam, const nerf_rende
         ray_out = c->d_rayfb;
     }
     const uint32_t n_passes_total = (uint32_t)((RH + rows_per_pass - 1) / rows_per_pass);
-    if (seq) { // per MLP launch: {u32 ray queue head, u32 live-sample count, u64 evaluated 32-sample chunks}
+    if (seq) { // per MLP launch: {u32 ray queue head, u32 live-sample count, u64 evaluated samples}
         const size_t slots = (size_t)n_passes_total * 3; // per pass: coarse, fine, hybrid f32 redo of the coarse pass
         if (slots > c->seq_slots) {
             size_t bytes = c->seq_slots * 16;
@@ -315,8 +317,8 @@ int nerfint::render_device(nerf_ctx *c, const nerf_camera *cam, const nerf_rende
         }
         HIP_TRY(c, hipMemsetAsync(c->d_seq, 0, slots * 16, st));
         const size_t pass_samples = rows_per_pass * RW * (size_t)M;
-        if ((rc = ensure_bytes(c, (void **)&c->d_h8, &c->h8_bytes, nerf_seq_h8_bytes(pass_samples)))) return rc;
-        if ((rc = ensure_bytes(c, (void **)&c->d_slot_point, &c->slot_point_bytes, (pass_samples + 128) * sizeof(unsigned int)))) return rc;
+        if (h8_export && (rc = ensure_bytes(c, (void **)&c->d_h8, &c->h8_bytes, nerf_seq_h8_bytes(pass_samples)))) return rc;
+        if (h8_export && (rc = ensure_bytes(c, (void **)&c->d_slot_point, &c->slot_point_bytes, (pass_samples + 128) * sizeof(unsigned int)))) return rc;
         if (hybrid && (rc = ensure_bytes(c, (void **)&c->d_flag_list, &c->flag_list_bytes, rows_per_pass * RW * sizeof(unsigned int)))) return rc;
     }
     recycle_render(c);
@@ -352,6 +354,7 @@ int nerfint::render_device(nerf_ctx *c, const nerf_camera *cam, const nerf_rende
             q.ray_dirs = c->d_dirs; q.t = t_in; q.far_ = cam->far_;
             q.origin[0] = cam->pos[0]; q.origin[1] = cam->pos[1]; q.origin[2] = cam->pos[2];
             q.sigma_out = sigma_out; q.ray_counter = ctr; q.live_count = ctr + 1; q.h8 = c->d_h8; q.slot_point = c->d_slot_point;
+            q.rgb_out = rgb_out; // f32: colour passes inside the trunk launch
             q.stats = (unsigned long long *)(ctr + 2);
             {
                 Timed t(c, st, kind_trunk, (uint64_t)n_rays * spr, timing);
@@ -360,13 +363,13 @@ int nerfint::render_device(nerf_ctx *c, const nerf_camera *cam, const nerf_rende
                                                   : nerf_trunk_seq_launch(q, rgb_out != nullptr, c->n_cus, st));
                 t.done(c->last_render);
             }
-            if (rgb_out) {
+            if (rgb_out && split_dtype(dt)) {
                 ColourArgs k{};
                 k.wstream = stream_of(net, dt); k.small_params = net.small; k.live_count = ctr + 1; k.h8 = c->d_h8; k.slot_point = c->d_slot_point;
                 k.ray_dirs = c->d_dirs; k.samples_per_ray = spr; k.rgb_out = rgb_out;
                 Timed t(c, st, 4, 0, timing);
                 HIP_TRY(c, dt == NERF_MLP_BF16X3 ? nerf_colour_x3_launch(k, c->n_cus, st)
-                           : dt == NERF_MLP_F16X2 ? nerf_colour_f16x2_launch(k, c->n_cus, st) : nerf_colour_launch(k, c->n_cus, st));
+                                                  : nerf_colour_f16x2_launch(k, c->n_cus, st));
                 t.done(c->last_render);
             }
             return NERF_OK;
@@ -417,7 +420,8 @@ int nerfint::render_device(nerf_ctx *c, const nerf_camera *cam, const nerf_rende
                 q.wstream = NC.wstream; q.small_params = NC.small; q.n_rays = n_rays; q.samples_per_ray = nc;
                 q.ray_dirs = c->d_dirs; q.t = c->d_tc; q.far_ = cam->far_;
                 q.origin[0] = cam->pos[0]; q.origin[1] = cam->pos[1]; q.origin[2] = cam->pos[2];
-                q.sigma_out = c->d_sc; q.ray_counter = hctr; q.live_count = hctr + 1; q.stats = (unsigned long long *)(hctr + 2);
+                q.sigma_out = c->d_sc; q.ray_counter = hctr; q.stats = (unsigned long long *)(hctr + 2);
+                q.live_count = nullptr; // hctr[1] is the LENGTH of the ray list below: this launch never exports (no colour head)
                 q.ray_list = c->d_flag_list; q.ray_list_count = hctr + 1; q.zero_fill_after_cut = 1;
                 {
                     Timed t(c, st, 0, 0, timing);
@@ -496,16 +500,16 @@ int nerfint::render_device(nerf_ctx *c, const nerf_camera *cam, const nerf_rende
         if (seq) {
             std::vector<unsigned int> h((size_t)passes * 3 * 4);
             HIP_TRY(c, hipMemcpy(h.data(), c->d_seq, h.size() * sizeof(unsigned int), hipMemcpyDeviceToHost));
-            uint64_t chunks[3] = {0, 0, 0}, live = 0;
+            uint64_t evaluated[3] = {0, 0, 0}, live = 0; // samples the trunk launches evaluated (a ray's last chunk may be partial)
             for (uint32_t k = 0; k < passes * 3; ++k) {
                 unsigned long long ch64;
                 memcpy(&ch64, &h[4 * (size_t)k + 2], sizeof ch64);
-                chunks[k % 3] += ch64;
+                evaluated[k % 3] += ch64;
                 if (k % 3 == 2) stats->n_hybrid_rays += h[4 * (size_t)k + 1]; // flagged rays redone in f32
                 else live += h[4 * (size_t)k + 1];
             }
-            stats->n_exec_coarse_trunk = (chunks[0] + chunks[2]) * 32;
-            stats->n_exec_fine_trunk = o->coarse_only ? 0 : chunks[1] * 32;
+            stats->n_exec_coarse_trunk = evaluated[0] + evaluated[2];
+            stats->n_exec_fine_trunk = o->coarse_only ? 0 : evaluated[1];
             stats->n_exec_colour = live;
             stats->n_colour_skipped_points = (o->coarse_only ? stats->n_coarse_points : stats->n_fine_points) - live;
         }
@@ -828,12 +832,32 @@ int nerf_stage_stratified(nerf_ctx *c, const nerf_camera *cam, int x0, int y0, i
     return NERF_OK;
 } NERF_CATCH(c)
 
+static int stage_resample(nerf_ctx *c, size_t n_rays, int nc, int nf, float far_, uint64_t seed, const uint32_t *pixel_index,
+                          const float *t_coarse, const float *sigma_coarse, const float *u, float *w_out, float *cdf_out,
+                          float *t_new_out, float *t_fine_out, float tau, uint8_t *flags_out);
+
 int nerf_stage_resample(nerf_ctx *c, size_t n_rays, int nc, int nf, float far_, uint64_t seed, const uint32_t *pixel_index,
                         const float *t_coarse, const float *sigma_coarse, const float *u, float *w_out, float *cdf_out,
                         float *t_new_out, float *t_fine_out) try {
+    return stage_resample(c, n_rays, nc, nf, far_, seed, pixel_index, t_coarse, sigma_coarse, u, w_out, cdf_out, t_new_out, t_fine_out, 0.0f, nullptr);
+} NERF_CATCH(c)
+
+int nerf_stage_hybrid_flags(nerf_ctx *c, size_t n_rays, int nc, int nf, float far_, uint64_t seed, const uint32_t *pixel_index,
+                            const float *t_coarse, const float *sigma_coarse, const float *u, float tau, uint8_t *flags_out,
+                            float *t_new_out) try {
+    if (!c) return fail(nullptr, NERF_ERR_INVALID, "ctx is NULL");
+    if (n_rays && !flags_out) return fail(c, NERF_ERR_INVALID, "NULL buffer");
+    if (!(tau >= 0.0f)) return fail(c, NERF_ERR_INVALID, "tau must be >= 0 (0 selects the context's threshold)");
+    return stage_resample(c, n_rays, nc, nf, far_, seed, pixel_index, t_coarse, sigma_coarse, u, nullptr, nullptr, t_new_out, nullptr,
+                          tau > 0.0f ? tau : c->hybrid_tau, flags_out);
+} NERF_CATCH(c)
+
+static int stage_resample(nerf_ctx *c, size_t n_rays, int nc, int nf, float far_, uint64_t seed, const uint32_t *pixel_index,
+                          const float *t_coarse, const float *sigma_coarse, const float *u, float *w_out, float *cdf_out,
+                          float *t_new_out, float *t_fine_out, float tau, uint8_t *flags_out) {
     if (!c) return fail(nullptr, NERF_ERR_INVALID, "ctx is NULL");
     if (n_rays == 0) return NERF_OK;
-    if (!t_coarse || !sigma_coarse || !t_fine_out) return fail(c, NERF_ERR_INVALID, "NULL buffer");
+    if (!t_coarse || !sigma_coarse || (!t_fine_out && !flags_out)) return fail(c, NERF_ERR_INVALID, "NULL buffer");
     if (nc < 3 || nf <= 0) return fail(c, NERF_ERR_INVALID, "resample needs nc >= 3 and nf > 0 (src/lib.rs:295-297)");
     if (!u && !pixel_index) return fail(c, NERF_ERR_INVALID, "either u or pixel_index must be given");
     if (resample_lds_bytes(nc, nf) > 160 * 1024 || n_rays > 0x7fffffff / (size_t)(nc + nf)) return fail(c, NERF_ERR_INVALID, "too many samples");
@@ -841,7 +865,7 @@ int nerf_stage_resample(nerf_ctx *c, size_t n_rays, int nc, int nf, float far_, 
     const size_t R = n_rays, M = (size_t)nc + nf;
     // layout in scratch (floats): tc, sc, u, w, cdf, tnew, tfine, pix
     const size_t o_tc = 0, o_sc = o_tc + R * nc, o_u = o_sc + R * nc, o_w = o_u + R * nf, o_cdf = o_w + R * nc,
-                 o_tn = o_cdf + R * (nc - 1), o_tf = o_tn + R * nf, o_px = o_tf + R * M, total = o_px + R;
+                 o_tn = o_cdf + R * (nc - 1), o_tf = o_tn + R * nf, o_px = o_tf + R * M, o_fl = o_px + R, total = o_fl + (R + 3) / 4;
     int rc;
     if ((rc = ensure_bytes(c, &c->d_scratch, &c->scratch_bytes, total * sizeof(float)))) return rc;
     float *d = (float *)c->d_scratch;
@@ -857,14 +881,16 @@ int nerf_stage_resample(nerf_ctx *c, size_t n_rays, int nc, int nf, float far_, 
     ra.u_in = u ? d + o_u : nullptr;
     ra.w_out = d + o_w; ra.cdf_out = d + o_cdf; ra.t_new_out = d + o_tn;
     ra.g.rw = 1; ra.g.rnx = 1; // unused when pixel_index/u are given
+    if (flags_out) { ra.flag_tau = tau; ra.flag_out = (unsigned char *)(d + o_fl); }
     HIP_TRY(c, launch_resample(ra, c->stream));
+    if (flags_out) HIP_TRY(c, hipMemcpyAsync(flags_out, d + o_fl, R, hipMemcpyDeviceToHost, c->stream));
     if (w_out) HIP_TRY(c, hipMemcpyAsync(w_out, d + o_w, R * nc * 4, hipMemcpyDeviceToHost, c->stream));
     if (cdf_out) HIP_TRY(c, hipMemcpyAsync(cdf_out, d + o_cdf, R * (nc - 1) * 4, hipMemcpyDeviceToHost, c->stream));
     if (t_new_out) HIP_TRY(c, hipMemcpyAsync(t_new_out, d + o_tn, R * nf * 4, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(t_fine_out, d + o_tf, R * M * 4, hipMemcpyDeviceToHost, c->stream));
+    if (t_fine_out) HIP_TRY(c, hipMemcpyAsync(t_fine_out, d + o_tf, R * M * 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return NERF_OK;
-} NERF_CATCH(c)
+}
 
 int nerf_stage_integrate(nerf_ctx *c, size_t n_rays, int n, float far_, const float *rgb, const float *sigma, const float *t,
                          float *rgb_out, float *w_out) try {

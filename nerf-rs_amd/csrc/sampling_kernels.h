@@ -34,6 +34,7 @@ struct ResampleArgs {
     float flag_tau = 0.0f;
     unsigned int *flag_count = nullptr; // device counter (zeroed by the caller)
     unsigned int *flag_list = nullptr;  // flagged ray indices, appended in arbitrary order
+    unsigned char *flag_out = nullptr;  // stage-test hook: n_rays bytes, 1 = this ray would be flagged (same decision, dense)
     // ... and, in a second launch, resample only the rays of a list (n_rays = capacity of the launch; the count lives on the device)
     const unsigned int *ray_list = nullptr;
     const unsigned int *ray_list_count = nullptr;

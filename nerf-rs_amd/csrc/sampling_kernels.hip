@@ -162,10 +162,11 @@ __global__ __launch_bounds__(256) void k_resample(ResampleArgs a) {
     // Hybrid sampling: predicted |dCDF| of this ray if its densities carry the split arithmetics' error against the f32 kernel --
     // an absolute part (1e-9 per sample that carries weight: |d sigma| ~ 1e-6 gives |dw| ~ 6e-8 over a ray's 62 bins; a sample with
     // weight exactly 0 has no error) and a relative one (7e-7 of the weight sum), divided by the normalising sum (a nearly empty ray
-    // has a tiny sum: its CDF is the most sensitive), times a safety factor 3.  A draw whose position would move by more than
+    // has a tiny sum: its CDF is the most sensitive), times a safety factor 4 (round 3: 3 left one ray of a random-weight fog scene at
+    // 1.0014e-5, tests/test_gpu_hybrid_validation.py; on the lego views unflagged rays move by <= 6.2e-6 with factor 3).  A draw whose position would move by more than
     // flag_tau (|dt| = bin width x |dCDF| / bin mass) flags the ray.
     const float sum_w = fmaxf(sum - (float)m * 1e-5f, 0.0f);
-    const float d_cdf = 3.0f * (1e-9f * (float)n_pos + 7e-7f * sum_w) / sum;
+    const float d_cdf = 4.0f * (1e-9f * (float)n_pos + 7e-7f * sum_w) / sum;
     bool light = false;
     for (int s = lane; s < nf; s += 64) {
         float u;
@@ -183,9 +184,10 @@ __global__ __launch_bounds__(256) void k_resample(ResampleArgs a) {
         const float tt = (u - cl) / denom;
         mg[nc + s] = bl + (bu - bl) * tt;
     }
-    if (a.flag_list) { // wave-uniform branch; every lane votes
+    if (a.flag_list || a.flag_out) { // wave-uniform branch; every lane votes
         const bool any_light = __any(light) || near_cut; // an ill-conditioned draw, or a transmittance within 0.1 % of the cut
-        if (any_light && lane == 0) a.flag_list[atomicAdd(a.flag_count, 1u)] = (unsigned)ray;
+        if (a.flag_list && any_light && lane == 0) a.flag_list[atomicAdd(a.flag_count, 1u)] = (unsigned)ray;
+        if (a.flag_out && lane == 0) a.flag_out[ray] = any_light ? 1 : 0;
     }
     for (int i = lane; i < nc; i += 64) mg[i] = t[i];
     wave_sync();

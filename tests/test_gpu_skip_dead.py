@@ -79,20 +79,41 @@ def test_skip_dead_full_frame(renderer, native, samples):
           f"colour {st.n_exec_colour / st.n_fine_points:.4f}, coarse trunk {st.n_exec_coarse_trunk / st.n_coarse_points:.4f}, "
           f"ms total {st.ms_total:.1f} (coarse {st.ms_coarse_mlp:.1f} fine {st.ms_fine_mlp:.1f} other {st.ms_other:.1f})")
     assert st.n_exec_fine_trunk < 0.99 * st.n_fine_points and st.n_exec_colour < 0.3 * st.n_fine_points
+    assert st.n_passes == 1 and st.n_mlp_launches == 2     # round 3: live samples are compacted in LDS, colour passes run inside the trunk launch
 
 
 def test_skip_dead_small_export_budget_means_more_passes(native, samples, monkeypatch):
-    """The compacted trunk outputs are sized for the worst case of a pass; a small budget only means more passes."""
+    """Split arithmetics still export the live samples' trunk outputs through HBM (two launches): that buffer is sized for the worst
+    case of a pass, and a small budget only means more passes.  The f32 kernel has no such buffer: one pass whatever the budget."""
     monkeypatch.setenv("NERF_MAX_EXPORT_BYTES", str(64 * 192 * 1024 * 5))      # five 64-ray rows of 192 samples
     with native.Renderer(0) as r:
         r.load_scene(SCENE)
         cam = native.camera_from_samples(samples, 800, 800, 64)
         crop = (368, 352, 64, 23)
-        img, st = native.render_image(r.coarse, r.fine, cam, 128, seed=0, crop=crop, skip_dead=True, return_stats=True)
+        img, st = native.render_image(r.coarse, r.fine, cam, 128, seed=0, crop=crop, skip_dead=True, dtype="f16x2", return_stats=True)
         assert st.n_passes == 5
+        f32, st32 = native.render_image(r.coarse, r.fine, cam, 128, seed=0, crop=crop, skip_dead=True, return_stats=True)
+        assert st32.n_passes == 1
         monkeypatch.delenv("NERF_MAX_EXPORT_BYTES")
-        ref = native.render_image(r.coarse, r.fine, cam, 128, seed=0, crop=crop)
-        assert np.array_equal(img, ref)
+        assert np.array_equal(img, native.render_image(r.coarse, r.fine, cam, 128, seed=0, crop=crop, dtype="f16x2"))
+        assert np.array_equal(f32, native.render_image(r.coarse, r.fine, cam, 128, seed=0, crop=crop))
+
+
+def test_skip_dead_dense_and_sparse_staging(renderer, native, samples):
+    """The in-LDS compaction of the f32 kernel: windows where nearly every chunk of every wave carries live samples (several colour
+    passes per trunk step, mid-step flushes) and windows where live samples trickle in (partial final flush), odd widths so that
+    the last workgroup has idle waves -- all bit-identical to the fused kernel."""
+    cam = native.camera_from_samples(samples, 800, 800, 64)
+    R = lambda **kw: native.render_image(renderer.coarse, renderer.fine, cam, 128, **kw)  # noqa: E731
+    for crop in ((390, 380, 3, 1), (396, 300, 5, 7), (330, 420, 131, 3), (0, 0, 800, 2), (200, 398, 401, 2)):
+        for seed in (0, 11):
+            a, st = native.render_image(renderer.coarse, renderer.fine, cam, 128, seed=seed, crop=crop, skip_dead=True, return_stats=True)
+            assert np.array_equal(a, R(seed=seed, crop=crop)), (crop, seed)
+            assert st.n_exec_colour <= st.n_exec_fine_trunk
+    # coarse_only + a 3-sample network pass (one partial chunk per ray, every wave nearly empty)
+    cam3 = native.camera_from_samples(samples, 800, 800, 3)
+    a = native.render_image(renderer.coarse, renderer.fine, cam3, 0, seed=1, crop=(380, 380, 33, 5), coarse_only=True, skip_dead=True)
+    assert np.array_equal(a, native.render_image(renderer.coarse, renderer.fine, cam3, 0, seed=1, crop=(380, 380, 33, 5), coarse_only=True))
 
 
 def test_skip_dead_argument_errors(renderer, native, samples):
