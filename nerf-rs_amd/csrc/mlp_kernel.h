@@ -32,6 +32,9 @@ hipError_t nerf_mlp_launch(const MlpArgs &a, bool full, int n_blocks, hipStream_
 // bf16-operand variant (mlp_kernel_bf16v2.hip): a.wstream is the output-tile-major stream (mlp_layout.h kChunks*Bf16V2)
 hipError_t nerf_mlp_bf16v2_init();
 hipError_t nerf_mlp_bf16v2_launch(const MlpArgs &a, bool full, int n_blocks, hipStream_t stream);
+// the same arithmetic on v_mfma_f32_16x16x32_bf16 (mlp_kernel_bf16v3.hip): its own piece contents, the same chunk counts
+hipError_t nerf_mlp_bf16v3_init();
+hipError_t nerf_mlp_bf16v3_launch(const MlpArgs &a, bool full, int n_blocks, hipStream_t stream);
 // f32 by three-way bf16 split (mlp_kernel_bf16x3.hip): a.wstream is the three-part stream (mlp_layout.h kChunks*X3)
 hipError_t nerf_mlp_bf16x3_init();
 hipError_t nerf_mlp_bf16x3_launch(const MlpArgs &a, bool full, int n_blocks, hipStream_t stream);

@@ -96,19 +96,31 @@ int ensure_workspace(nerf_ctx *c, size_t rays, size_t nc, size_t m, bool need_rg
 
 int upload_packed(nerf_ctx *c, int which, const std::vector<float> &ws, const std::vector<float> &sm);
 
+// The bf16 kernel: mlp_kernel_bf16v2.hip (32x32x16).  A variant build with -DNERF_BF16_V3=1 (make variant; round-3 experiment, see
+// DESIGN 4.3) links mlp_kernel_bf16v3.hip (16x16x32) instead: same arithmetic, same results, measured 6 % slower on the full kernel.
+#ifndef NERF_BF16_V3
+#define NERF_BF16_V3 0
+#endif
+static constexpr bool g_bf16_v2 = !NERF_BF16_V3;
+
 // weight stream + launcher of the selected arithmetic
 static bool valid_dtype(int d) { return d == NERF_MLP_F32 || d == NERF_MLP_BF16 || d == NERF_MLP_BF16X3 || d == NERF_MLP_F16X2; }
 static bool split_dtype(int d) { return d == NERF_MLP_BF16X3 || d == NERF_MLP_F16X2; } // f32-accurate operand-splitting arithmetics
 static const float *stream_of(const DevNet &n, int dtype) {
     if (dtype == NERF_MLP_BF16X3) return (const float *)n.wstream_x3;
     if (dtype == NERF_MLP_F16X2) return (const float *)n.wstream_x2;
-    return dtype == NERF_MLP_F32 ? n.wstream : (const float *)n.wstream_bf16v2;
+    if (dtype == NERF_MLP_F32) return n.wstream;
+    return g_bf16_v2 ? (const float *)n.wstream_bf16v2 : (const float *)n.wstream_bf16v3;
 }
 static hipError_t launch_mlp(const nerf_ctx *c, int dtype, const MlpArgs &a, bool full, hipStream_t st) {
     if (dtype == NERF_MLP_F32) return nerf_mlp_launch(a, full, c->n_cus, st);
     if (dtype == NERF_MLP_BF16X3) return nerf_mlp_bf16x3_launch(a, full, c->n_cus, st);
     if (dtype == NERF_MLP_F16X2) return nerf_mlp_f16x2_launch(a, full, c->n_cus, st);
+#if NERF_BF16_V3
+    return nerf_mlp_bf16v3_launch(a, full, c->n_cus, st);
+#else
     return nerf_mlp_bf16v2_launch(a, full, c->n_cus, st);
+#endif
 }
 
 // v1 stream -> v2 stream: the 1-KiB pieces are identical (lane l, element j = W[row(tile, 8 ks + j, l >> 5)][32 nt + (l & 31)]);
@@ -134,6 +146,67 @@ static void bf16_v2_from_v1(const std::vector<uint16_t> &v1, std::vector<uint16_
     v2.resize((size_t)kChunksFullBf16V2 * kChunkBytesBf16V2 / 2, (uint16_t)0);
 }
 
+// v1 order (f32 values) -> the stream of mlp_kernel_bf16v3.hip (v_mfma_f32_16x16x32_bf16): per layer, per output tile nt, per k-step ks
+// (K = 32), per 16-feature half fh one 1-KiB piece: lane l = (i = l & 15, g = l >> 4), element e = W[row(ks, g, e)][32 nt + 16 fh + i].
+// Hidden k-steps: k-slot (g, e) = feature 4 g + e (e < 4) or 16 + 4 g + e - 4 of input tile ks (the C/D layout of two 16x16 output
+// halves packed pairwise); encoding k-steps: slot 32 ks + 8 g + e = the reference's feature index (src/network.rs:263-330).
+static void bf16_v3_from_v1(const std::vector<float> &v1f, std::vector<uint16_t> &v3) {
+    using namespace nerfmlp;
+    v3.clear();
+    v3.reserve((size_t)kChunksFullBf16V2 * kChunkBytesBf16V2 / 2);
+    int pos_inv[64][3], dir_inv[32][3]; // reference feature -> (input tile, register, lane-half) of the 32x32 layouts
+    for (auto &x : pos_inv) x[0] = -1;
+    for (auto &x : dir_inv) x[0] = -1;
+    for (int tt = 0; tt < 2; ++tt)
+        for (int r = 0; r < 16; ++r)
+            for (int h = 0; h < 2; ++h) {
+                const int f = posSlotFeature(16 * tt + r, h);
+                if (f >= 0) { pos_inv[f][0] = tt; pos_inv[f][1] = r; pos_inv[f][2] = h; }
+            }
+    for (int r = 0; r < 16; ++r)
+        for (int h = 0; h < 2; ++h) {
+            const int f = dirSlotFeature(r, h);
+            if (f >= 0) { dir_inv[f][0] = 0; dir_inv[f][1] = r; dir_inv[f][2] = h; }
+        }
+    size_t base = 0; // v1 pieces
+    // kind of k-step ks: 0 = activation tile `tile`, 1 = position-encoding slots 32 * tile .., 2 = direction-encoding slots
+    auto layer = [&](int n_tiles_v1, int NT, int KS, auto kind_of) {
+        for (int nt = 0; nt < NT; ++nt)
+            for (int ks = 0; ks < KS; ++ks)
+                for (int fh = 0; fh < 2; ++fh)
+                    for (int l = 0; l < 64; ++l)
+                        for (int e = 0; e < 8; ++e) {
+                            const int i = l & 15, g = l >> 4;
+                            int kind, tile;
+                            kind_of(ks, kind, tile);
+                            int tt = -1, r = 0, h = 0;
+                            if (kind == 0) {
+                                const int f = e < 4 ? 4 * g + e : 16 + 4 * g + (e - 4);
+                                tt = tile; h = (f >> 2) & 1; r = (f & 3) + 4 * (f >> 3);
+                            } else if (kind == 1) {
+                                const int s = 32 * tile + 8 * g + e;
+                                if (s < 63 && pos_inv[s][0] >= 0) { tt = pos_inv[s][0]; r = pos_inv[s][1]; h = pos_inv[s][2]; }
+                            } else {
+                                const int s = 8 * g + e;
+                                if (s < 27 && dir_inv[s][0] >= 0) { tt = n_tiles_v1 - 1; r = dir_inv[s][1]; h = dir_inv[s][2]; }
+                            }
+                            float v = 0.0f;
+                            if (tt >= 0) {
+                                const size_t piece = base + ((size_t)(tt * 2 + (r >> 3)) * NT + nt);
+                                v = v1f[(piece * 64 + (size_t)(16 * fh + i + 32 * h)) * 8 + (r & 7)];
+                            }
+                            v3.push_back(f32_to_bf16_rne(v));
+                        }
+        base += (size_t)n_tiles_v1 * 2 * NT;
+    };
+    layer(2, 8, 2, [](int ks, int &kind, int &tile) { kind = 1; tile = ks; });
+    for (int i = 0; i < 4; ++i) layer(8, 8, 8, [](int ks, int &kind, int &tile) { kind = 0; tile = ks; });
+    layer(10, 8, 10, [](int ks, int &kind, int &tile) { if (ks < 2) { kind = 1; tile = ks; } else { kind = 0; tile = ks; } });
+    for (int i = 0; i < 3; ++i) layer(8, 8, 8, [](int ks, int &kind, int &tile) { kind = 0; tile = ks; });
+    layer(9, 4, 9, [](int ks, int &kind, int &tile) { if (ks < 8) { kind = 0; tile = ks; } else { kind = 2; tile = 0; } });
+    v3.resize((size_t)kChunksFullBf16V2 * kChunkBytesBf16V2 / 2, (uint16_t)0);
+}
+
 // All bf16-family streams come from one f32 array in the first bf16 design's piece order (host_util.h).
 int upload_bf16_family(nerf_ctx *c, int which, const std::vector<float> &v1f) {
     if (v1f.size() != (size_t)nerfmlp::kPiecesV1 * 512) return fail(c, NERF_ERR_SHAPE, "internal: bf16 piece array has the wrong size");
@@ -145,6 +218,13 @@ int upload_bf16_family(nerf_ctx *c, int which, const std::vector<float> &v1f) {
     if (x3.size() != (size_t)nerfmlp::kChunksFullX3 * nerfmlp::kChunkBytesX3 / 2) return fail(c, NERF_ERR_SHAPE, "internal: bf16x3 stream size");
     if (!d.wstream_bf16v2) HIP_TRY(c, hipMalloc((void **)&d.wstream_bf16v2, v2.size() * sizeof(uint16_t)));
     HIP_TRY(c, hipMemcpy(d.wstream_bf16v2, v2.data(), v2.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    if (!g_bf16_v2) {
+        std::vector<uint16_t> v3;
+        bf16_v3_from_v1(v1f, v3);
+        if (v3.size() != v2.size()) return fail(c, NERF_ERR_SHAPE, "internal: bf16 v3 stream size");
+        if (!d.wstream_bf16v3) HIP_TRY(c, hipMalloc((void **)&d.wstream_bf16v3, v3.size() * sizeof(uint16_t)));
+        HIP_TRY(c, hipMemcpy(d.wstream_bf16v3, v3.data(), v3.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    }
     if (!d.wstream_x3) HIP_TRY(c, hipMalloc((void **)&d.wstream_x3, x3.size() * sizeof(uint16_t)));
     HIP_TRY(c, hipMemcpy(d.wstream_x3, x3.data(), x3.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
     std::vector<uint16_t> x2;
@@ -581,6 +661,9 @@ int nerf_create(int device_id, nerf_ctx **out) try {
         if (!init_done.count(device_id)) {
             e1 = nerf_mlp_init();
             if (e1 == hipSuccess) e1 = nerf_mlp_bf16v2_init();
+#if NERF_BF16_V3
+            if (e1 == hipSuccess) e1 = nerf_mlp_bf16v3_init();
+#endif
             if (e1 == hipSuccess) e1 = nerf_mlp_bf16x3_init();
             if (e1 == hipSuccess) e1 = nerf_seq_init();
             if (e1 == hipSuccess) e1 = nerf_seq_x3_init();
@@ -604,7 +687,7 @@ void nerf_destroy(nerf_ctx *c) {
     if (!c) return;
     DeviceGuard dg(c->device);
     (void)hipDeviceSynchronize();
-    for (auto &n : c->net) { if (n.wstream) (void)hipFree(n.wstream); if (n.small) (void)hipFree(n.small); if (n.wstream_bf16v2) (void)hipFree(n.wstream_bf16v2); if (n.wstream_x3) (void)hipFree(n.wstream_x3); if (n.wstream_x2) (void)hipFree(n.wstream_x2); }
+    for (auto &n : c->net) { if (n.wstream) (void)hipFree(n.wstream); if (n.small) (void)hipFree(n.small); if (n.wstream_bf16v2) (void)hipFree(n.wstream_bf16v2); if (n.wstream_bf16v3) (void)hipFree(n.wstream_bf16v3); if (n.wstream_x3) (void)hipFree(n.wstream_x3); if (n.wstream_x2) (void)hipFree(n.wstream_x2); }
     float *ptrs[] = {c->d_dirs, c->d_tc, c->d_sc, c->d_rgbc, c->d_tf, c->d_sf, c->d_rgbf, c->d_rayfb, c->d_out};
     for (float *p : ptrs) if (p) (void)hipFree(p);
     if (c->d_scratch) (void)hipFree(c->d_scratch);

@@ -14,6 +14,7 @@ namespace nerfint {
 struct DevNet {
     float *wstream = nullptr, *small = nullptr;
     uint16_t *wstream_bf16v2 = nullptr; // bf16 pieces in output-tile-major order (mlp_kernel_bf16v2.hip)
+    uint16_t *wstream_bf16v3 = nullptr; // bf16 pieces for the 16x16x32 kernel (mlp_kernel_bf16v3.hip)
     uint16_t *wstream_x3 = nullptr;     // three bf16 parts per weight (mlp_kernel_bf16x3.hip)
     uint16_t *wstream_x2 = nullptr;     // two f16 parts per weight (mlp_kernel_f16x2.hip); NULL if a weight exceeds the f16 range
     bool loaded = false;
