@@ -328,10 +328,10 @@ def main():
                       "executed_fraction_of_fp32_mfma_roofline": exec_flop / (ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
                       "device_ms": {"total": st.ms_total, "coarse_trunk": st.ms_coarse_mlp, "fine_trunk_plus_colour": st.ms_fine_mlp,
                                     "other": st.ms_other, "passes": st.n_passes},
-                      "note": "opt-in skip_dead (exact): ray-sequential trunk kernel walks each ray front to back in 32-sample chunks off a "
-                              "device-side ray queue and retires it at the reference's T < 1e-4 cut (src/lib.rs:276-279); samples with "
-                              "weight > 0 export the trunk output (1 KiB) to a compacted buffer, a second launch runs bottleneck + viewdirs + "
-                              "rgb on those only"}
+                      "note": "opt-in skip_dead (exact): ray-sequential kernel walks each ray front to back in 32-sample chunks off a "
+                              "device-side ray queue and retires it at the reference's T < 1e-4 cut (src/lib.rs:276-279); the trunk outputs of the "
+                              "samples with weight > 0 are compacted in LDS and bottleneck + viewdirs + rgb run on them in 64-column passes inside "
+                              "the same launch (round 3: no HBM export, one pass per frame)"}
         # ... and with hybrid sampling on top: f16x2 sampling pass, ill-conditioned rays redone in f32, exact-f32 fine pass
         def dead_hyb_step(stats=False):
             return N.render_image(r.coarse, r.fine, cam, args.fine, seed=args.seed, ssaa=args.ssaa, skip_dead=True, hybrid_sampling=True,
@@ -462,8 +462,11 @@ def main():
         value = n_rays * args.steps * (world if weak else 1) / dt  # whole-job rays/s over all ranks
         # executed flops of the dominant launches: a skipped sample still runs dense0..7 + alpha (sigma-only cost)
         flops_dom = pts_dom * N.FLOP_PER_POINT_FULL - n_dom * skipped_per_launch * (N.FLOP_PER_POINT_FULL - N.FLOP_PER_POINT_SIGMA)
-        if dead_stats is not None:  # dominant launch = the ray-sequential fine trunk (dense0..7 + alpha on the samples in front of the cut)
-            flops_dom = (n_dom / max(dead_stats.n_passes, 1)) * dead_stats.n_exec_fine_trunk * N.FLOP_PER_POINT_SIGMA  # one launch per pass
+        if dead_stats is not None:
+            # dominant launch = the ray-sequential fine kernel: dense0..7 + alpha on the samples in front of the cut and -- f32: in the same
+            # launch (colour passes on the LDS-compacted live samples); split arithmetics: in a second launch, not priced here -- the colour head
+            flops_dom = (n_dom / max(dead_stats.n_passes, 1)) * (dead_stats.n_exec_fine_trunk * N.FLOP_PER_POINT_SIGMA +
+                                                                  (0 if split else dead_stats.n_exec_colour * (N.FLOP_PER_POINT_FULL - N.FLOP_PER_POINT_SIGMA)))
         ach = mfma_per_flop * flops_dom / (ms_dom * 1e-3) / 1e12 if ms_dom > 0 else 0.0
         traffic, traffic_src, traffic_why = pmc_traffic_bytes(
             (f"void nerf_trunk_seq_kernel_{sfx}<" if split else "void nerf_trunk_seq_kernel<") if args.skip_dead else
@@ -500,13 +503,15 @@ def main():
                          "traffic_source": (f"HBM bytes per launch from this round's committed rocprofv3 PMC passes of the same command ({traffic_src}; "
                                             "2 x FETCH_SIZE + WRITE_SIZE in separate --pmc runs; counters cannot be read from inside the run); "
                                             "algorithmic: 20 B/point") if traffic_src else traffic_why,
-                         "kernel": ((f"nerf_trunk_seq_kernel_{sfx}" if split else "nerf_trunk_seq_kernel") + "<EXPORT=true> (fine network, ray-sequential trunk; executed flops)"
+                         "kernel": ((f"nerf_trunk_seq_kernel_{sfx}<EXPORT=true> (fine network, ray-sequential trunk; executed flops)" if split else
+                                     "nerf_trunk_seq_kernel<EXPORT=true> (fine network, ray-sequential trunk + in-kernel colour passes; executed flops)")
                                     if dead_stats is not None else
                                     ("nerf_mlp_kernel_bf16v2" if bf16 else "nerf_mlp_kernel_bf16x3" if x3 else "nerf_mlp_kernel_f16x2" if x2 else "nerf_mlp_kernel") +
                                     "<FULL=true, MODE_RAYS> (fine network)"),
                          "launches": n_dom, "avg_launch_ms": ms_dom / max(n_dom, 1),
                          "points_per_launch": pts_dom // max(n_dom, 1),
-                         "flop_per_point": N.FLOP_PER_POINT_SIGMA if dead_stats is not None else N.FLOP_PER_POINT_FULL},
+                         "flop_per_point": N.FLOP_PER_POINT_SIGMA if dead_stats is not None else N.FLOP_PER_POINT_FULL,
+                         "flop_per_live_point_colour_head": (N.FLOP_PER_POINT_FULL - N.FLOP_PER_POINT_SIGMA) if dead_stats is not None and not split else None},
         }
         if per_rank is not None:
             line["per_rank"] = per_rank  # max/min over ranks: render (HIP events around the band render), gather (events around the collective)

@@ -1,4 +1,4 @@
-//! Raw bindings to libnerf_mi355x.so.  One-to-one with include/nerf_mi355x.h (ABI version 2): every function the header
+//! Raw bindings to libnerf_mi355x.so.  One-to-one with include/nerf_mi355x.h (ABI version 3): every function the header
 //! declares is declared here with the same number of arguments (tests/test_host_logic.py parses both and compares);
 //! layouts are `#[repr(C)]` mirrors of `nerf_camera`, `nerf_render_opts`, `nerf_stats` -- call `check_layouts()` once at
 //! start-up to compare their sizes with the library's (`nerf_abi_struct_sizes`).
@@ -66,6 +66,7 @@ pub struct nerf_stats {
     pub n_exec_fine_trunk: u64,
     pub n_exec_colour: u64,
     pub n_hybrid_rays: u64,
+    pub n_nonfinite_points: u64,
 }
 
 /// `gather` of `nerf_render_image_multi`
@@ -86,6 +87,7 @@ pub const NERF_NET_FINE: c_int = 1;
 
 extern "C" {
     pub fn nerf_abi_version() -> c_int;
+    pub fn nerf_build_variant() -> *const c_char;
     pub fn nerf_abi_struct_sizes(camera: *mut usize, render_opts: *mut usize, stats: *mut usize);
     pub fn nerf_create(device_id: c_int, out: *mut *mut nerf_ctx) -> c_int;
     pub fn nerf_destroy(ctx: *mut nerf_ctx);
@@ -147,9 +149,9 @@ pub fn check_layouts() -> Result<(), String> {
     let (mut a, mut b, mut c) = (0usize, 0usize, 0usize);
     unsafe { nerf_abi_struct_sizes(&mut a, &mut b, &mut c) };
     let mine = (std::mem::size_of::<nerf_camera>(), std::mem::size_of::<nerf_render_opts>(), std::mem::size_of::<nerf_stats>());
-    if (a, b, c) == mine && unsafe { nerf_abi_version() } == 2 {
+    if (a, b, c) == mine && unsafe { nerf_abi_version() } == 3 {
         Ok(())
     } else {
-        Err(format!("libnerf_mi355x: ABI {} with struct sizes {:?}, this crate expects ABI 2 with {:?}", unsafe { nerf_abi_version() }, (a, b, c), mine))
+        Err(format!("libnerf_mi355x: ABI {} with struct sizes {:?}, this crate expects ABI 3 with {:?}", unsafe { nerf_abi_version() }, (a, b, c), mine))
     }
 }

@@ -113,6 +113,10 @@ typedef struct {
     uint64_t n_exec_fine_trunk;    /* fine network, dense0..7 + alpha */
     uint64_t n_exec_colour;        /* bottleneck + viewdirs + rgb (fine network, or the coarse one when coarse_only) */
     uint64_t n_hybrid_rays;        /* hybrid_sampling: rays whose coarse pass was redone in f32 (counted in n_exec_coarse_trunk too) */
+    uint64_t n_nonfinite_points;   /* split arithmetics: evaluations in which an operand left the arithmetic's range (NERF_MLP_F16X2: an
+                                    * activation beyond 65 504 -- every value is watched as it is split, one v_max3 per pair) or whose density
+                                    * pre-activation was not finite.  0 in every validated configuration; non-zero means the frame is WRONG
+                                    * there (f16 overflow yields finite garbage, not NaN).  nerf_forward_batch_ex fails with NERF_ERR_STATE. */
 } nerf_stats;
 
 /* ---- lifecycle ------------------------------------------------------------------------------------------ */
@@ -247,7 +251,11 @@ int nerf_stage_hybrid_flags(nerf_ctx *ctx, size_t n_rays, int nc, int nf, float 
 int nerf_stage_integrate(nerf_ctx *ctx, size_t n_rays, int n, float far_, const float *rgb_aos, const float *sigma,
                          const float *t, float *rgb_out, float *w_out);
 
-/* ABI version: bumped on any signature or struct change (2: multi-GPU entry points, skip_dead, n_exec_* statistics). */
+/* "" for the product build.  Tuning / timing-only builds (make variant: some of their switches make results WRONG on purpose)
+ * report "NAME: compile definitions"; a host should refuse such a library outside experiments (the Python loader does). */
+const char *nerf_build_variant(void);
+/* ABI version: bumped on any signature or struct change (2: multi-GPU entry points, skip_dead, n_exec_* statistics; 3: nerf_stats.
+ * n_nonfinite_points, nerf_check_network_blob, nerf_stage_hybrid_flags, nerf_build_variant). */
 int nerf_abi_version(void);
 /* sizeof(nerf_camera), sizeof(nerf_render_opts), sizeof(nerf_stats) as this library was built: lets a binding written in
  * another language (the Rust `-sys` crate, ctypes) check its struct mirrors at start-up. */

@@ -36,12 +36,13 @@ class CStats(C.Structure):
                 ("ms_total", C.c_double), ("ms_coarse_mlp", C.c_double), ("ms_fine_mlp", C.c_double),
                 ("ms_other", C.c_double), ("n_mlp_launches", C.c_uint32), ("n_passes", C.c_uint32),
                 ("n_colour_skipped_points", C.c_uint64), ("n_exec_coarse_trunk", C.c_uint64), ("n_exec_fine_trunk", C.c_uint64),
-                ("n_exec_colour", C.c_uint64), ("n_hybrid_rays", C.c_uint64)]
+                ("n_exec_colour", C.c_uint64), ("n_hybrid_rays", C.c_uint64), ("n_nonfinite_points", C.c_uint64)]
 
 
 # name -> (restype, argtypes); kept in sync with include/nerf_mi355x.h (tests/test_host_logic.py::test_abi_exports_every_declared_symbol checks the header)
 PROTOTYPES = {
     "nerf_abi_version": (C.c_int, []),
+    "nerf_build_variant": (C.c_char_p, []),
     "nerf_abi_struct_sizes": (None, [C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "nerf_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
     "nerf_destroy": (None, [C.c_void_p]),
@@ -92,7 +93,9 @@ PROTOTYPES = {
 
 
 def lib_path():
-    """In-tree extension; NERF_MI355X_LIB selects another build of the same library (tuning variants)."""
+    """The in-tree extension.  NERF_MI355X_LIB names another build of the same library (tuning variants, `make variant`): such a
+    build reports a non-empty nerf_build_variant() and is only accepted with NERF_ALLOW_VARIANT=1 (the tools/ scripts set it) --
+    timing-only switches make results wrong on purpose, so a variant can never silently stand in for the product."""
     return os.environ.get("NERF_MI355X_LIB") or os.path.join(_HERE, "libnerf_mi355x.so")
 
 
@@ -118,6 +121,9 @@ def load_library():
             fn = getattr(L, name)  # AttributeError if the symbol is not exported
             fn.restype = res
             fn.argtypes = args
+        tag = L.nerf_build_variant()
+        if tag and os.environ.get("NERF_ALLOW_VARIANT") != "1":
+            raise ImportError(f"{path} is a tuning variant ({tag.decode()}), not the product build; set NERF_ALLOW_VARIANT=1 for experiments")
         sizes = [C.c_size_t() for _ in range(3)]
         L.nerf_abi_struct_sizes(*[C.byref(x) for x in sizes])
         mine = (C.sizeof(CCamera), C.sizeof(COpts), C.sizeof(CStats))

@@ -23,6 +23,7 @@ struct MlpArgs {
     int skip_empty;                   // full kernels: skip the colour head of tiles whose 128 sigmas are all 0 (exact)
     unsigned long long *skip_counter; // optional: number of skipped 128-point tiles (atomic)
     unsigned long long *clock_out; // optional diagnostic: per workgroup {shader cycles, 100 MHz ticks} of the tile loop
+    unsigned int *nonfinite;       // optional (split arithmetics): += points whose density pre-activation is NaN / inf (f16 range overflow)
 };
 
 // Sets the dynamic-LDS attribute of every kernel instantiation on the current device.
@@ -66,6 +67,7 @@ struct SeqArgs {
     const unsigned int *ray_list;
     const unsigned int *ray_list_count;
     int zero_fill_after_cut;
+    unsigned int *nonfinite;   // optional (split arithmetics): += points whose density pre-activation is NaN / inf
 };
 struct ColourArgs {
     const float *wstream;      // the same stream (bottleneck + viewdirs part is used)
@@ -76,6 +78,7 @@ struct ColourArgs {
     const float *ray_dirs;
     int samples_per_ray;
     float *rgb_out;            // n x 3, scattered by sample index; zero-filled by the caller
+    unsigned int *nonfinite;   // optional: += samples for which an operand left the arithmetic's range
 };
 hipError_t nerf_seq_init();
 size_t nerf_seq_h8_bytes(size_t n_samples);

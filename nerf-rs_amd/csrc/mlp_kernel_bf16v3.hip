@@ -42,6 +42,19 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 #ifndef NERF_BV3_SCHED_BARRIER
 #define NERF_BV3_SCHED_BARRIER 1
 #endif
+// timing-only diagnostics (results are garbage): which resource bounds the kernel
+#ifndef NERF_BV3_DIAG_NO_DMA
+#define NERF_BV3_DIAG_NO_DMA 0
+#endif
+#ifndef NERF_BV3_DIAG_NO_BARRIER
+#define NERF_BV3_DIAG_NO_BARRIER 0
+#endif
+#ifndef NERF_BV3_DIAG_NO_EPILOGUE
+#define NERF_BV3_DIAG_NO_EPILOGUE 0
+#endif
+#ifndef NERF_BV3_DIAG_NO_LDS
+#define NERF_BV3_DIAG_NO_LDS 0
+#endif
 
 namespace {
 
@@ -100,9 +113,16 @@ __device__ __forceinline__ void pipe_start(PipeV &P) {
 template <int PH>
 __device__ __forceinline__ bf16x8 pipe_take(PipeV &P) {
     if constexpr (PH == 8) {
+#if NERF_BV3_DIAG_NO_BARRIER
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (kRS - 3)) : "memory");
+#else
         asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(4 * (kRS - 3)) : "memory");
+#endif
         pipe_next_chunk(P);
     }
+#if NERF_BV3_DIAG_NO_LDS
+    if constexpr (PH != 0) { u32x4 a = P.a[0]; asm volatile("" : "+v"(a)); return __builtin_bit_cast(bf16x8, a); }
+#endif
     static_assert(kAhead % 2 == 0, "paired reads need an even prefetch distance");
     if constexpr ((PH & 1) == 0) {
         asm volatile("" : "+v"(P.a[PH % 8]), "+v"(P.a[(PH + 1) % 8])); // one s_waitcnt for the pair
@@ -136,6 +156,9 @@ __device__ __forceinline__ void glds_piece_off(uint32_t lane16, const char *gsrc
 
 template <int PH>
 __device__ __forceinline__ void pipe_dma(PipeV &P) {
+#if NERF_BV3_DIAG_NO_DMA
+    return;
+#endif
     if constexpr (PH >= 9 && (PH & 1) == 1) glds_piece_off<((PH - 9) / 2) * 1024>(P.lane16, P.cur_src, P.cur_dst);
 }
 
@@ -170,6 +193,9 @@ struct LaneOfs { int bias, alpha, rgb; };
 // HEAD 0: convert only; 1: convert + alpha partial sums; 2: alpha only (sigma kernels); 3: rgb partial sums only.
 template <int PR, bool RELU, int HEAD, int NTI>
 __device__ __forceinline__ void convert_pair(const AccT &acc, Bk &dst, Heads &H, const LDS_AS float *small, const LaneOfs &L) {
+#if NERF_BV3_DIAG_NO_EPILOGUE
+    if constexpr (PR != 0) return;
+#endif
     constexpr int cg = PR >> 2, q = PR & 3, fh = q >> 1, r0 = 2 * (q & 1);
     const float x0 = acc.v[fh][cg][r0], x1 = acc.v[fh][cg][r0 + 1];
     if constexpr (HEAD == 1 || HEAD == 2) { // alpha = sum_F w[F] relu(h8[F]) in f32 (src/network.rs:216)

@@ -113,7 +113,7 @@ __device__ __forceinline__ void prep_pair(const f32x16 &in, B3 &b) {
 }
 
 template <bool RELU, int KS>
-__device__ __forceinline__ void prep_all(const f32x16 &in, B3 &b) {
+__device__ __forceinline__ void prep_all(const f32x16 &in, B3 &b, PipeX &) {
     prep_pair<RELU, KS, 0>(in, b); prep_pair<RELU, KS, 1>(in, b); prep_pair<RELU, KS, 2>(in, b); prep_pair<RELU, KS, 3>(in, b);
 }
 
@@ -165,6 +165,9 @@ __device__ __forceinline__ void k_step(f32x16 (&out)[8], const B3 &bc, const f32
         X3_PIN();
     });
 }
+
+// bf16 parts have f32's exponent range: nothing can leave it (the f16x2 arithmetic checks its operands here)
+__device__ __forceinline__ void range_check(PipeX &, unsigned int *, bool) {}
 
 using PipeS = PipeX;
 using BS = B3;

@@ -39,6 +39,9 @@ constexpr int kCB = kChunkBytesF16X2, kRS = kRingSlotsF16X2;
 #endif
 constexpr int kAhead = NERF_F16X2_AHEAD; // operand prefetch distance in units (1..3); a unit is three MFMAs = 96 cycles
 // Timing-only diagnostics (results are WRONG with any of these set; never shipped): what the non-MFMA cycles are spent on
+#ifndef NERF_F16X2_RANGE_WATCH
+#define NERF_F16X2_RANGE_WATCH 1 // 0 (variant builds): without the per-pair range watch, to price it
+#endif
 #ifndef NERF_F16X2_DIAG_NO_BARRIER
 #define NERF_F16X2_DIAG_NO_BARRIER 0
 #endif
@@ -70,6 +73,7 @@ struct PipeH {
     uint32_t ring_addr, wr_slot_off, next_off, stream_bytes;
     const char *gbase, *cur_src;
     uint32_t cur_dst, lane16;
+    float amax = 0.0f;            // largest |value| this lane has split since the last range_check (f16 overflows at 65 504)
 };
 
 template <int OFF>
@@ -165,7 +169,7 @@ struct B2 { u32x4 h, l; }; // the two f16x8 fragments of one k-step's B operand
 struct PrepState { f32x2 x; uint32_t h; };
 
 template <bool RELU, int KS, int Q, int STAGE>
-__device__ __forceinline__ void prep_stage(const f32x16 &in, B2 &b, PrepState &st) {
+__device__ __forceinline__ void prep_stage(const f32x16 &in, B2 &b, PrepState &st, float &amax) {
 #if NERF_F16X2_DIAG_NO_PREP
     if constexpr (STAGE == 2) { b.h[Q] = 0x3c003c00u; b.l[Q] = 0u; }
     return;
@@ -174,6 +178,11 @@ __device__ __forceinline__ void prep_stage(const f32x16 &in, B2 &b, PrepState &s
         float x0 = in[8 * KS + 2 * Q], x1 = in[8 * KS + 2 * Q + 1];
         asm volatile("" : "+v"(x0), "+v"(x1)); // keep the accumulator reads here (hipcc otherwise hoists a whole layer's)
         if (RELU) { x0 = relu(x0); x1 = relu(x1); }
+        // Range watch (one v_max3_f32 per pair): beyond 65 504 the f16 parts become (inf, -inf), the products NaN, and a NaN does not
+        // survive the integer-max ReLU of the next layer -- the outputs would be finite and WRONG (measured: sigma 296 instead of 1.5e7)
+#if NERF_F16X2_RANGE_WATCH
+        asm volatile("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(amax) : "v"(x0), "v"(x1)); // as asm: the plain expression made hipcc spill 800 registers
+#endif
         st.x = f32x2{x0, x1};
     } else if constexpr (STAGE == 1) {
         const f16x2 hh = __builtin_convertvector(st.x, f16x2);
@@ -186,14 +195,23 @@ __device__ __forceinline__ void prep_stage(const f32x16 &in, B2 &b, PrepState &s
 }
 
 template <bool RELU, int KS, int Q>
-__device__ __forceinline__ void prep_pair(const f32x16 &in, B2 &b) {
+__device__ __forceinline__ void prep_pair(const f32x16 &in, B2 &b, float &amax) {
     PrepState st;
-    prep_stage<RELU, KS, Q, 0>(in, b, st); prep_stage<RELU, KS, Q, 1>(in, b, st); prep_stage<RELU, KS, Q, 2>(in, b, st);
+    prep_stage<RELU, KS, Q, 0>(in, b, st, amax); prep_stage<RELU, KS, Q, 1>(in, b, st, amax); prep_stage<RELU, KS, Q, 2>(in, b, st, amax);
 }
 
 template <bool RELU, int KS>
-__device__ __forceinline__ void prep_all(const f32x16 &in, B2 &b) {
-    prep_pair<RELU, KS, 0>(in, b); prep_pair<RELU, KS, 1>(in, b); prep_pair<RELU, KS, 2>(in, b); prep_pair<RELU, KS, 3>(in, b);
+__device__ __forceinline__ void prep_all(const f32x16 &in, B2 &b, PipeH &P) {
+    prep_pair<RELU, KS, 0>(in, b, P.amax); prep_pair<RELU, KS, 1>(in, b, P.amax); prep_pair<RELU, KS, 2>(in, b, P.amax); prep_pair<RELU, KS, 3>(in, b, P.amax);
+}
+
+// End of a tile / chunk: did any operand of this column leave the f16 range?  Counts columns (both lane-halves of a column hold
+// features of the same point) into the optional device counter and re-arms the watch.
+__device__ __forceinline__ void range_check(PipeH &P, unsigned int *counter, bool valid) {
+    unsigned long long bad = __ballot(valid && !(P.amax <= 65504.0f)); // NaN counts as out of range
+    P.amax = 0.0f;
+    bad = (bad | (bad >> 32)) & 0xffffffffull;
+    if (counter && bad && (threadIdx.x & 63) == 0) atomicAdd(counter, (unsigned)__popcll(bad));
 }
 
 #define X2_PIN() __builtin_amdgcn_sched_barrier(0)
@@ -224,18 +242,18 @@ __device__ __forceinline__ void k_step(f32x16 (&out)[8], const B2 &bc, const f32
         X2_PIN();
         pipe_prefetch<U>(P);
         if constexpr (!pairwise || even) pipe_dma<U>(P);
-        if constexpr (HAS_NEXT && !pairwise && (NT == 4 || even)) prep_stage<NRELU, NKS, Q, 0>(nin, bn, st);
+        if constexpr (HAS_NEXT && !pairwise && (NT == 4 || even)) prep_stage<NRELU, NKS, Q, 0>(nin, bn, st, P.amax);
         X2_PIN();
         out[nt] = MFMA16(a1, b2, out[nt]);
         X2_PIN();
-        if constexpr (HAS_NEXT && pairwise) prep_stage<NRELU, NKS, Q, (even ? 0 : 2)>(nin, bn, st);
-        if constexpr (HAS_NEXT && !pairwise && (NT == 4 || even)) prep_stage<NRELU, NKS, Q, 1>(nin, bn, st);
+        if constexpr (HAS_NEXT && pairwise) prep_stage<NRELU, NKS, Q, (even ? 0 : 2)>(nin, bn, st, P.amax);
+        if constexpr (HAS_NEXT && !pairwise && (NT == 4 || even)) prep_stage<NRELU, NKS, Q, 1>(nin, bn, st, P.amax);
         X2_PIN();
         out[nt] = MFMA16(a1, b1, out[nt]);
         X2_PIN();
-        if constexpr (HAS_NEXT && pairwise && even) prep_stage<NRELU, NKS, Q, 1>(nin, bn, st);
+        if constexpr (HAS_NEXT && pairwise && even) prep_stage<NRELU, NKS, Q, 1>(nin, bn, st, P.amax);
         if constexpr (pairwise && !even) pipe_dma<U>(P);
-        if constexpr (HAS_NEXT && !pairwise && (NT == 4 || even)) prep_stage<NRELU, NKS, Q, 2>(nin, bn, st);
+        if constexpr (HAS_NEXT && !pairwise && (NT == 4 || even)) prep_stage<NRELU, NKS, Q, 2>(nin, bn, st, P.amax);
         X2_PIN();
     });
 }

@@ -1,7 +1,7 @@
 // mlp_split_kernels.hip.h -- the kernel bodies shared by the "f32 by operand splitting" arithmetics: bf16x3
 // (mlp_kernel_bf16x3.hip: three bf16 parts, six products) and f16x2 (mlp_kernel_f16x2.hip: two f16 parts, three products).
 // Textually included at the end of each of those files, after the file has defined, in an anonymous namespace, its
-// primitives -- PipeS (weight-stream pipeline) with pipe_start(), BS (split B operand), prep_all, k_step, kCB / kRS,
+// primitives -- PipeS (weight-stream pipeline) with pipe_start(), BS (split B operand), prep_all, k_step, range_check, kCB / kRS,
 // kSplitChunksSigma / kSplitChunksFull, kSplitLdsBytes, kSplitWaveBytes (the layers built from them -- tile_steps, eight_tiles,
 // hidden_layer, load_bias, alpha_head -- are defined here, once) --
 // and the SPLIT_* names of the kernels and host functions it instantiates here:
@@ -61,12 +61,15 @@ __device__ __forceinline__ void hidden_layer(f32x16 (&in)[8], f32x16 (&out)[8], 
     load_bias<8>(out, bias, h);
     BS b;
     asm volatile("" : "+a"(in[0]));
-    prep_all<RELU, 0>(in[0], b);
+    prep_all<RELU, 0>(in[0], b, P);
     eight_tiles<8, RELU>(in, out, b, P);
     tile_steps<8, RELU, true, false, false, false>(in[7], in[7], out, b, P);
 }
 
-__device__ __forceinline__ float alpha_head(const f32x16 (&Y)[8], const LDS_AS float *small, int h) {
+// `nonfinite` (optional device counter): points whose density pre-activation is NaN / inf.  With NERF_MLP_F16X2 an activation beyond
+// the f16 range splits into (inf, -inf) and turns into NaN in the next layer; fmaxf below would silently return 0 for it.  One v_cmp
+// per tile makes that observable (nerf_stats.n_nonfinite_points; nerf_forward_batch_ex fails with NERF_ERR_STATE).
+__device__ __forceinline__ float alpha_head(const f32x16 (&Y)[8], const LDS_AS float *small, int h, unsigned int *nonfinite, bool valid) {
     const LDS_AS f32x4 *w = (const LDS_AS f32x4 *)(small + kAlphaWOff + h * 128);
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
 #pragma unroll
@@ -82,7 +85,12 @@ __device__ __forceinline__ float alpha_head(const f32x16 (&Y)[8], const LDS_AS f
             a3 = fmaf(wv[3], relu(x3), a3);
         }
     }
-    return fmaxf(xhalf_sum((a0 + a1) + (a2 + a3)) + small[kMiscOff + 0], 0.f);
+    const float pre = xhalf_sum((a0 + a1) + (a2 + a3)) + small[kMiscOff + 0];
+    if (nonfinite) {
+        const unsigned long long bad = __ballot(valid && !(fabsf(pre) <= 3.0e38f)) & 0xffffffffull; // one lane-half per point
+        if (bad && (threadIdx.x & 63) == 0) atomicAdd(nonfinite, (unsigned)__popcll(bad));
+    }
+    return fmaxf(pre, 0.f);
 }
 
 } // namespace
@@ -131,7 +139,7 @@ __global__ __launch_bounds__(256, 1) void SPLIT_KERNEL_FUSED(const MlpArgs A) {
         f32x16 X[8], Y[8];
         BS b;
         load_bias<8>(X, small + kBiasOff + 0 * 256, h);          // dense0 (src/network.rs:204)
-        prep_all<false, 0>(E[0], b);
+        prep_all<false, 0>(E[0], b, P);
         tile_steps<8, false, false, true, false, false>(E[0], E[1], X, b, P);
         tile_steps<8, false, false, false, false, false>(E[1], E[1], X, b, P);
         hidden_layer<true>(X, Y, small + kBiasOff + 1 * 256, P, h);
@@ -139,7 +147,7 @@ __global__ __launch_bounds__(256, 1) void SPLIT_KERNEL_FUSED(const MlpArgs A) {
         hidden_layer<true>(X, Y, small + kBiasOff + 3 * 256, P, h);
         hidden_layer<true>(Y, X, small + kBiasOff + 4 * 256, P, h);
         load_bias<8>(Y, small + kBiasOff + 5 * 256, h);          // dense5 on [encoding ; h4] (:209-210)
-        prep_all<false, 0>(E[0], b);
+        prep_all<false, 0>(E[0], b, P);
         tile_steps<8, false, false, true, false, false>(E[0], E[1], Y, b, P);
         tile_steps<8, false, false, true, true, true>(E[1], X[0], Y, b, P);
         eight_tiles<8, true>(X, Y, b, P);
@@ -147,8 +155,9 @@ __global__ __launch_bounds__(256, 1) void SPLIT_KERNEL_FUSED(const MlpArgs A) {
         hidden_layer<true>(Y, X, small + kBiasOff + 6 * 256, P, h);
         hidden_layer<true>(X, Y, small + kBiasOff + 7 * 256, P, h);
 
-        const float sigma = alpha_head(Y, small, h);
+        const float sigma = alpha_head(Y, small, h, A.nonfinite, valid);
         if (valid && h == 0) A.sigma_out[i] = sigma;
+        if (!FULL) range_check(P, A.nonfinite, valid);
 
         if (FULL && A.skip_empty) { // exact empty-tile skip, see mlp_kernel.hip
             LDS_AS int *vote = (LDS_AS int *)(lds + kRS * kCB) + kMiscOff + 8;
@@ -158,6 +167,7 @@ __global__ __launch_bounds__(256, 1) void SPLIT_KERNEL_FUSED(const MlpArgs A) {
                     A.rgb_out[3 * (size_t)i + 0] = 0.f; A.rgb_out[3 * (size_t)i + 1] = 0.f; A.rgb_out[3 * (size_t)i + 2] = 0.f;
                 }
                 if (A.skip_counter && tid == 0) atomicAdd(A.skip_counter, 1ull);
+                range_check(P, A.nonfinite, valid);
                 asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory"); // in-flight chunks landed; ring idle
                 pipe_start(P);
                 continue;
@@ -171,7 +181,7 @@ __global__ __launch_bounds__(256, 1) void SPLIT_KERNEL_FUSED(const MlpArgs A) {
             f32x16 (&V)[8] = Y;                                          // Y is dead after the bottleneck
             load_bias<4>(V, small + kBiasViewOff, h);
             asm volatile("" : "+a"(X[0]));
-            prep_all<false, 0>(X[0], b);
+            prep_all<false, 0>(X[0], b, P);
             eight_tiles<4, false>(X, V, b, P);
             tile_steps<4, false, true, true, false, false>(X[7], D, V, b, P);
             tile_steps<4, false, false, false, false, false>(D, D, V, b, P);
@@ -182,6 +192,7 @@ __global__ __launch_bounds__(256, 1) void SPLIT_KERNEL_FUSED(const MlpArgs A) {
                 A.rgb_out[3 * (size_t)i + 1] = c[1];
                 A.rgb_out[3 * (size_t)i + 2] = c[2];
             }
+            range_check(P, A.nonfinite, valid);
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -234,7 +245,7 @@ __global__ __launch_bounds__(256, 1) void SPLIT_KERNEL_TRUNK(const SeqArgs A) {
         f32x16 X[8], Y[8];
         BS b;
         load_bias<8>(X, small + kBiasOff + 0 * 256, h);
-        prep_all<false, 0>(E[0], b);
+        prep_all<false, 0>(E[0], b, P);
         tile_steps<8, false, false, true, false, false>(E[0], E[1], X, b, P);
         tile_steps<8, false, false, false, false, false>(E[1], E[1], X, b, P);
         hidden_layer<true>(X, Y, small + kBiasOff + 1 * 256, P, h);
@@ -242,14 +253,15 @@ __global__ __launch_bounds__(256, 1) void SPLIT_KERNEL_TRUNK(const SeqArgs A) {
         hidden_layer<true>(X, Y, small + kBiasOff + 3 * 256, P, h);
         hidden_layer<true>(Y, X, small + kBiasOff + 4 * 256, P, h);
         load_bias<8>(Y, small + kBiasOff + 5 * 256, h);
-        prep_all<false, 0>(E[0], b);
+        prep_all<false, 0>(E[0], b, P);
         tile_steps<8, false, false, true, false, false>(E[0], E[1], Y, b, P);
         tile_steps<8, false, false, true, true, true>(E[1], X[0], Y, b, P);
         eight_tiles<8, true>(X, Y, b, P);
         tile_steps<8, true, true, false, false, false>(X[7], X[7], Y, b, P);
         hidden_layer<true>(Y, X, small + kBiasOff + 6 * 256, P, h);
         hidden_layer<true>(X, Y, small + kBiasOff + 7 * 256, P, h);
-        const float sigma = alpha_head(Y, small, h);
+        const float sigma = alpha_head(Y, small, h, A.nonfinite, c.valid);
+        range_check(P, A.nonfinite, c.valid);
         chunk_finish<EXPORT>(W, A, c, sigma, Y, lane, p, h);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -284,13 +296,14 @@ __global__ __launch_bounds__(256, 1) void SPLIT_KERNEL_COLOUR(const ColourArgs A
         load_bias<4>(V, small + kBiasViewOff, h);
         BS b;
         asm volatile("" : "+a"(X[0]));
-        prep_all<false, 0>(X[0], b);
+        prep_all<false, 0>(X[0], b, P);
         eight_tiles<4, false>(X, V, b, P);
         tile_steps<4, false, true, true, false, false>(X[7], D, V, b, P);
         tile_steps<4, false, false, false, false, false>(D, D, V, b, P);
         float rgb[3];
         rgb_head(V, small, h, rgb);
         colour_store(A, c, rgb, h);
+        range_check(P, A.nonfinite, c.valid);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }

@@ -373,11 +373,25 @@ int nerfint::render_device(nerf_ctx *c, const nerf_camera *cam, const nerf_rende
     // skip_dead in a split arithmetic (two launches): the compacted trunk outputs are sized for the worst case (every sample of a pass
     // live, 1 KiB each).  The f32 kernel compacts in LDS and runs its colour passes in the same launch: no buffer, no extra passes.
     const bool h8_export = seq && split_dtype(dtype);
+    // Budget and allocation of that buffer are ONE critical section per process: contexts that share a device (nerf_render_image_multi's
+    // worker threads) would otherwise each claim half of the same free memory and fail in hipMalloc.  A context keeps its buffer while
+    // later renders fit; a render that needs less than a quarter of it gives it back (shrinks).
+    static std::mutex h8_mu;
+    std::unique_lock<std::mutex> h8_lock(h8_mu, std::defer_lock);
     if (h8_export) {
+        h8_lock.lock();
         size_t budget = c->max_export_bytes, free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) // never more than half of what the device can still give (plus what we already hold)
             budget = std::min(budget, (free_b + c->h8_bytes) / 2);
-        pass_cap = std::min<size_t>(pass_cap, std::max<size_t>(1, budget / ((size_t)M * 1024)));
+        const size_t row_bytes = (size_t)RW * M * 1024;
+        if (row_bytes > budget) {
+            char msg[256];
+            snprintf(msg, sizeof msg, "skip_dead in a split arithmetic exports 1 KiB per sample: one ray row of this render (%d rays x %d samples) needs "
+                     "%zu MiB, the budget is %zu MiB (NERF_MAX_EXPORT_BYTES, free device memory / 2); render a narrower crop or use NERF_MLP_F32",
+                     RW, M, row_bytes >> 20, budget >> 20);
+            return fail(c, NERF_ERR_INVALID, msg);
+        }
+        pass_cap = std::min<size_t>(pass_cap, budget / ((size_t)M * 1024));
     }
     if ((size_t)RW > pass_cap && (size_t)RW * M > (size_t)0x3fffffff) return fail(c, NERF_ERR_INVALID, "ray row too wide for one pass");
     const size_t rows_per_pass = std::max<size_t>(1, std::min<size_t>(RH, pass_cap / (size_t)RW));
@@ -397,8 +411,17 @@ int nerfint::render_device(nerf_ctx *c, const nerf_camera *cam, const nerf_rende
         }
         HIP_TRY(c, hipMemsetAsync(c->d_seq, 0, slots * 16, st));
         const size_t pass_samples = rows_per_pass * RW * (size_t)M;
-        if (h8_export && (rc = ensure_bytes(c, (void **)&c->d_h8, &c->h8_bytes, nerf_seq_h8_bytes(pass_samples)))) return rc;
-        if (h8_export && (rc = ensure_bytes(c, (void **)&c->d_slot_point, &c->slot_point_bytes, (pass_samples + 128) * sizeof(unsigned int)))) return rc;
+        if (h8_export) {
+            const size_t need = nerf_seq_h8_bytes(pass_samples);
+            if (c->d_h8 && need < c->h8_bytes / 4) { // a much smaller render: give the big buffer back
+                HIP_TRY(c, hipDeviceSynchronize());
+                HIP_TRY(c, hipFree(c->d_h8));
+                c->d_h8 = nullptr; c->h8_bytes = 0;
+            }
+            if ((rc = ensure_bytes(c, (void **)&c->d_h8, &c->h8_bytes, need))) return rc;
+            if ((rc = ensure_bytes(c, (void **)&c->d_slot_point, &c->slot_point_bytes, (pass_samples + 128) * sizeof(unsigned int)))) return rc;
+            h8_lock.unlock();
+        }
         if (hybrid && (rc = ensure_bytes(c, (void **)&c->d_flag_list, &c->flag_list_bytes, rows_per_pass * RW * sizeof(unsigned int)))) return rc;
     }
     recycle_render(c);
@@ -410,6 +433,8 @@ int nerfint::render_device(nerf_ctx *c, const nerf_camera *cam, const nerf_rende
         ~RenderScope() { if (!ok) for (auto &p : c->last_render) if (p.kind == 1) p.kind = 2; }
     } scope{c};
     if (o->skip_empty && c->d_skip) HIP_TRY(c, hipMemsetAsync(c->d_skip, 0, sizeof(unsigned long long), st));
+    const bool watch_range = c->d_nonfinite && (split_dtype(dtype) || split_dtype(dtype_coarse));
+    if (watch_range) HIP_TRY(c, hipMemsetAsync(c->d_nonfinite, 0, sizeof(unsigned int), st));
     const bool timing = true;
     RayGenArgs g = make_raygen(*cam, s);
     const DevNet &NC = c->net[NERF_NET_COARSE], &NF = c->net[NERF_NET_FINE];
@@ -436,6 +461,7 @@ int nerfint::render_device(nerf_ctx *c, const nerf_camera *cam, const nerf_rende
             q.sigma_out = sigma_out; q.ray_counter = ctr; q.live_count = ctr + 1; q.h8 = c->d_h8; q.slot_point = c->d_slot_point;
             q.rgb_out = rgb_out; // f32: colour passes inside the trunk launch
             q.stats = (unsigned long long *)(ctr + 2);
+            q.nonfinite = split_dtype(dt) ? c->d_nonfinite : nullptr;
             {
                 Timed t(c, st, kind_trunk, (uint64_t)n_rays * spr, timing);
                 HIP_TRY(c, dt == NERF_MLP_BF16X3 ? nerf_trunk_seq_x3_launch(q, rgb_out != nullptr, c->n_cus, st)
@@ -446,7 +472,7 @@ int nerfint::render_device(nerf_ctx *c, const nerf_camera *cam, const nerf_rende
             if (rgb_out && split_dtype(dt)) {
                 ColourArgs k{};
                 k.wstream = stream_of(net, dt); k.small_params = net.small; k.live_count = ctr + 1; k.h8 = c->d_h8; k.slot_point = c->d_slot_point;
-                k.ray_dirs = c->d_dirs; k.samples_per_ray = spr; k.rgb_out = rgb_out;
+                k.ray_dirs = c->d_dirs; k.samples_per_ray = spr; k.rgb_out = rgb_out; k.nonfinite = c->d_nonfinite;
                 Timed t(c, st, 4, 0, timing);
                 HIP_TRY(c, dt == NERF_MLP_BF16X3 ? nerf_colour_x3_launch(k, c->n_cus, st)
                                                   : nerf_colour_f16x2_launch(k, c->n_cus, st));
@@ -463,6 +489,7 @@ int nerfint::render_device(nerf_ctx *c, const nerf_camera *cam, const nerf_rende
         a.n_points = n_rays * nc; a.samples_per_ray = nc; a.t = c->d_tc;
         a.sigma_out = c->d_sc; a.rgb_out = o->coarse_only ? c->d_rgbc : nullptr; // sigma-only launch otherwise
         a.skip_empty = o->skip_empty; a.skip_counter = o->skip_empty ? c->d_skip : nullptr; // only full kernels look at it
+        a.nonfinite = split_dtype(dtype_coarse) ? c->d_nonfinite : nullptr;
         if (seq) {
             if ((rc = seq_pass(NC, dtype_coarse, nc, c->d_tc, c->d_sc, o->coarse_only ? c->d_rgbc : nullptr, 3 * (int)passes, o->coarse_only ? 1 : 0))) return rc;
         } else {
@@ -521,6 +548,7 @@ int nerfint::render_device(nerf_ctx *c, const nerf_camera *cam, const nerf_rende
         a.n_points = n_rays * M; a.samples_per_ray = M; a.t = t_fine;
         a.sigma_out = c->d_sf; a.rgb_out = c->d_rgbf;
         a.clock_out = c->d_clock; // NULL unless NERF_DEBUG_CLOCK=1
+        a.nonfinite = split_dtype(dtype) ? c->d_nonfinite : nullptr;
         c->clock_valid = c->d_clock != nullptr;
         if (seq) {
             if ((rc = seq_pass(NF, dtype, M, t_fine, c->d_sf, c->d_rgbf, 3 * (int)passes + 1, 1))) return rc;
@@ -568,6 +596,11 @@ int nerfint::render_device(nerf_ctx *c, const nerf_camera *cam, const nerf_rende
             HIP_TRY(c, hipEventElapsedTime(&ms, c->last_render.front().a, c->last_render.back().b));
             stats->ms_total = ms;
         }
+        if (watch_range) {
+            unsigned int bad = 0;
+            HIP_TRY(c, hipMemcpy(&bad, c->d_nonfinite, sizeof bad, hipMemcpyDeviceToHost));
+            stats->n_nonfinite_points = bad;
+        }
         if (o->skip_empty && c->d_skip) {
             unsigned long long tiles = 0;
             HIP_TRY(c, hipMemcpy(&tiles, c->d_skip, sizeof tiles, hipMemcpyDeviceToHost));
@@ -608,7 +641,7 @@ int nerfint::render_device(nerf_ctx *c, const nerf_camera *cam, const nerf_rende
 
 extern "C" {
 
-int nerf_abi_version(void) { return 2; }
+int nerf_abi_version(void) { return 3; }
 
 void nerf_abi_struct_sizes(size_t *camera, size_t *render_opts, size_t *stats) {
     if (camera) *camera = sizeof(nerf_camera);
@@ -652,6 +685,7 @@ int nerf_create(int device_id, nerf_ctx **out) try {
         if (atoi(env) > 0 && hipMalloc((void **)&c->d_clock, (size_t)c->n_cus * 2 * sizeof(unsigned long long)) != hipSuccess) c->d_clock = nullptr;
     }
     if (hipMalloc((void **)&c->d_skip, sizeof(unsigned long long)) != hipSuccess) c->d_skip = nullptr;
+    if (hipMalloc((void **)&c->d_nonfinite, sizeof(unsigned int)) != hipSuccess) c->d_nonfinite = nullptr;
     // kernel attributes (dynamic LDS sizes) are per device, not per context: set them once per device and process
     static std::mutex init_mu;
     static std::set<int> init_done;
@@ -693,6 +727,7 @@ void nerf_destroy(nerf_ctx *c) {
     if (c->d_scratch) (void)hipFree(c->d_scratch);
     if (c->d_clock) (void)hipFree(c->d_clock);
     if (c->d_skip) (void)hipFree(c->d_skip);
+    if (c->d_nonfinite) (void)hipFree(c->d_nonfinite);
     if (c->d_seq) (void)hipFree(c->d_seq);
     if (c->d_h8) (void)hipFree(c->d_h8);
     if (c->d_slot_point) (void)hipFree(c->d_slot_point);
@@ -788,6 +823,7 @@ static int forward_device(nerf_ctx *c, int which, int dtype, const float *d_pts,
     if (dtype == NERF_MLP_F16X2 && !c->net[which].wstream_x2) return fail(c, NERF_ERR_STATE, "NERF_MLP_F16X2 is unavailable for this network: a weight exceeds the f16 range");
     a.wstream = stream_of(c->net[which], dtype); a.small_params = c->net[which].small;
     a.n_points = (int)n; a.pts_soa = d_pts; a.dirs_aos = d_dirs; a.sigma_out = d_sigma; a.rgb_out = d_rgb;
+    a.nonfinite = split_dtype(dtype) ? c->d_nonfinite : nullptr;
     HIP_TRY(c, launch_mlp(c, dtype, a, true, (hipStream_t)stream));
     return NERF_OK;
 }
@@ -806,10 +842,20 @@ int nerf_forward_batch_ex(nerf_ctx *c, int which, int dtype, const float *pts, c
     float *d_pts = (float *)c->d_scratch, *d_dirs = d_pts + 3 * n, *d_rgb = d_dirs + 3 * n, *d_sig = d_rgb + 3 * n;
     HIP_TRY(c, hipMemcpyAsync(d_pts, pts, 3 * n * sizeof(float), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipMemcpyAsync(d_dirs, dirs, 3 * n * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    const bool watch = split_dtype(dtype) && c->d_nonfinite;
+    if (watch) HIP_TRY(c, hipMemsetAsync(c->d_nonfinite, 0, sizeof(unsigned int), c->stream));
     if ((rc = forward_device(c, which, dtype, d_pts, d_dirs, n, d_rgb, d_sig, c->stream))) return rc;
     HIP_TRY(c, hipMemcpyAsync(rgb, d_rgb, 3 * n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipMemcpyAsync(sigma, d_sig, n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    unsigned int bad = 0;
+    if (watch) HIP_TRY(c, hipMemcpyAsync(&bad, c->d_nonfinite, sizeof bad, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (bad) {
+        char msg[320];
+        snprintf(msg, sizeof msg, "%u of %zu points: an operand left the range of the split arithmetic (NERF_MLP_F16X2: |activation| <= 65504) or a "
+                 "density was not finite; the outputs are not usable -- use NERF_MLP_BF16X3 or NERF_MLP_F32", bad, n);
+        return fail(c, NERF_ERR_STATE, msg);
+    }
     return NERF_OK;
 } NERF_CATCH(c)
 

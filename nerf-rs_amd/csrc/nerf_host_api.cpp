@@ -55,7 +55,13 @@ int read_blob_file(const std::string &path, std::vector<float> &ws, std::vector<
     catch (const std::exception &e) { return fail_noctx(NERF_ERR_INVALID, std::string("internal error: ") + e.what()); } \
     catch (...) { return fail_noctx(NERF_ERR_INVALID, "internal error"); }
 
+#ifndef NERF_BUILD_VARIANT
+#define NERF_BUILD_VARIANT ""
+#endif
+
 extern "C" {
+
+const char *nerf_build_variant(void) { return NERF_BUILD_VARIANT; }
 
 int nerf_pack_network_dir(const char *dir, const char *blob_path) try {
     if (!dir || !blob_path) return fail_noctx(NERF_ERR_INVALID, "NULL argument");

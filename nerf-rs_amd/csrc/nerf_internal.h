@@ -50,8 +50,10 @@ struct nerf_ctx {
     unsigned int *d_slot_point = nullptr; size_t slot_point_bytes = 0;
     unsigned int *d_flag_list = nullptr; size_t flag_list_bytes = 0; // hybrid sampling: rays whose coarse pass is redone in f32
     float hybrid_tau = 1e-5f;                                        // a draw predicted to move by more than this (in t) flags its ray
-    size_t max_export_bytes = (size_t)48 << 30; // budget of d_h8: bounds the rays per pass in skip_dead mode (NERF_MAX_EXPORT_BYTES)
+    size_t max_export_bytes = (size_t)16 << 30; // budget of d_h8: bounds the rays per pass of skip_dead in a SPLIT arithmetic (NERF_MAX_EXPORT_BYTES);
+                                                // 16 GiB = 8 passes per 800x800 frame, 1.4 % slower than one pass of 128 GiB
     unsigned long long *d_skip = nullptr;  // device counter of skipped 128-point tiles (skip_empty)
+    unsigned int *d_nonfinite = nullptr;   // device counter of non-finite density pre-activations (split arithmetics)
     unsigned long long *d_clock = nullptr; // diagnostic: per-workgroup {cycles, 100 MHz ticks} of the last fine-MLP launch
     bool clock_valid = false;
     size_t max_rays_per_pass = (size_t)1 << 20;

@@ -77,6 +77,40 @@ def test_f16x2_range(renderer, oracle_nets):
             assert ds.max() <= 3e-4 and np.abs(rgb - ergb).max() <= 1e-4
 
 
+def test_f16x2_overflow_is_observable(native, samples, tmp_path):
+    """Beyond its range the arithmetic must FAIL LOUDLY, not return zeros: a network whose hidden activations exceed 65 504 (the lego
+    coarse net with dense0 scaled by 2000 and dense1 by 50: weights still inside the f16 range, so the mode stays available) makes nerf_forward_batch_ex
+    return NERF_ERR_STATE with the count of affected points, nerf_stats.n_nonfinite_points counts them in a render, and bf16x3 (f32
+    exponent range) evaluates the same network correctly."""
+    import shutil
+    d = tmp_path / "hot"
+    shutil.copytree(os.path.join(SCENE, "coarse"), d)
+    for name, k in (("dense0_kernel", 2000.0), ("dense1_kernel", 50.0)):     # dense1's outputs reach ~1e6: dense2's inputs leave the f16 range
+        w = np.fromfile(d / f"{name}.bin", "<f4") * np.float32(k)
+        assert np.abs(w).max() < 65504
+        w.astype("<f4").tofile(d / f"{name}.bin")
+    rng = np.random.default_rng(5)
+    pts = rng.uniform(-2, 2, size=(3, 4096)).astype(np.float32)
+    v = rng.normal(size=(4096, 3)); dirs = (v / np.linalg.norm(v, axis=1, keepdims=True)).astype(np.float32)
+    with native.Renderer(0) as r:
+        hot = native.load_network_from_dir(r, 0, d)
+        native.load_network_from_dir(r, 1, os.path.join(SCENE, "fine"))
+        rgb, sg = hot.forward_batch(pts, dirs, dtype="bf16x3")
+        f32 = hot.forward_batch(pts, dirs, dtype="f32")
+        assert np.isfinite(sg).all() and np.abs(sg - f32[1]).max() <= 1e-4 * (1 + np.abs(f32[1]).max())
+        with pytest.raises(native.NerfError) as e:
+            hot.forward_batch(pts, dirs, dtype="f16x2")
+        assert e.value.code == -6 and "left the range" in e.value.msg and "65504" in e.value.msg
+        cam = native.camera_from_samples(samples, 64, 64, 64)
+        r.coarse, r.fine = hot, native.Network(r, 1)
+        _, st = native.render_image(r.coarse, r.fine, cam, 128, seed=0, dtype="f16x2", coarse_only=True, return_stats=True)
+        assert st.n_nonfinite_points > 0
+        _, st = native.render_image(r.coarse, r.fine, cam, 128, seed=0, dtype="f16x2", skip_dead=True, hybrid_sampling=True, return_stats=True)
+        assert st.n_nonfinite_points > 0                      # the hybrid sampling pass runs the hot coarse network in f16x2
+        _, st = native.render_image(r.coarse, r.fine, cam, 128, seed=0, dtype="f16x2", return_stats=True)
+        assert st.n_nonfinite_points == 0                     # plain f16x2: the coarse (sampling) pass is f32, the fine network is in range
+
+
 def test_f16x2_render_gate1_and_skip_dead(renderer, native, samples):
     cam = native.camera_from_samples(samples, 800, 800, 64)
     g = golden("crop_c3_800_64_128.npz")

@@ -50,13 +50,13 @@ def test_hybrid_gate1_other_poses_and_sample_counts(renderer, native, oracle, or
         assert 0 < st.n_hybrid_rays < st.n_rays
 
 
-def _random_scene(root, seed):
+def _random_scene(root, seed, alpha_bias=(0.02, 0.03), alpha_scale=0.25):
     """Two random networks of the reference's architecture in its directory format (He-scaled weights; alpha bias > 0 so that
     the density field is alive: a fog of varying density instead of a surface -- very different weight statistics from lego)."""
     rng = np.random.default_rng(seed)
     shapes = [("dense0", 63, 256)] + [(f"dense{i}", 256, 256) for i in range(1, 5)] + [("dense5", 319, 256), ("dense6", 256, 256),
               ("dense7", 256, 256), ("bottleneck", 256, 256), ("viewdirs", 283, 128), ("rgb", 128, 3), ("alpha", 256, 1)]
-    for which, alpha_bias in (("coarse", 0.02), ("fine", 0.03)):
+    for which, a_bias in (("coarse", alpha_bias[0]), ("fine", alpha_bias[1])):
         d = root / which
         d.mkdir(parents=True)
         lines = []
@@ -64,8 +64,8 @@ def _random_scene(root, seed):
             w = (rng.normal(size=(k, n)) * np.sqrt(2.0 / k)).astype("<f4")
             b = (rng.normal(size=(n,)) * 0.1).astype("<f4")
             if name == "alpha":
-                w *= 0.25
-                b[:] = alpha_bias
+                w *= alpha_scale
+                b[:] = a_bias
             w.tofile(d / f"{name}_kernel.bin"); b.tofile(d / f"{name}_bias.bin")
             lines += [f"{name}_kernel {k} {n}", f"{name}_bias {n}"]
         (d / "shapes.txt").write_text("\n".join(lines) + "\n")
@@ -92,6 +92,7 @@ def test_hybrid_random_weight_scene(native, oracle, samples, tmp_path):
         cam = native.camera_from_samples(samples, 64, 64, 64)
         f32, s0 = native.render_image(coarse, fine, cam, 128, seed=5, skip_dead=True, return_stats=True)
         _fog_gate(f32, ref)
+        assert np.array_equal(f32, native.render_image(coarse, fine, cam, 128, seed=5))
         assert s0.n_exec_colour > 0.05 * s0.n_fine_points and ref.std() > 0.01     # a live, non-trivial field
         for dt in ("f16x2", "bf16x3", "f32"):
             img, st = native.render_image(coarse, fine, cam, 128, seed=5, dtype=dt, skip_dead=True, hybrid_sampling=True, return_stats=True)
@@ -100,6 +101,24 @@ def test_hybrid_random_weight_scene(native, oracle, samples, tmp_path):
                   f"mean {d.mean():.2e}; redone {st.n_hybrid_rays / st.n_rays:.3f}")
             _fog_gate(img, ref)                                  # no worse against the oracle than the exact-f32 path itself ...
             assert d.mean() <= 2e-6 and (d.max(axis=2) > 5e-4).mean() <= 2e-3   # ... and the same picture as the f32 frame
+
+
+def test_skip_dead_dense_fog_every_sample_live(native, samples, tmp_path):
+    """A uniform fog of density ~2 keeps EVERY sample live (T stays above 1e-4 over the whole ray): all four waves stage 32 columns in
+    every step of the f32 skip_dead kernel, colour passes run in the MIDDLE of the staging loop (a wave's samples do not fit) as well
+    as at its end, back to back -- the paths the lego scene rarely takes.  Still the bits of the fused kernel."""
+    root = _random_scene(tmp_path / "fog", 7, alpha_bias=(2.0, 2.0), alpha_scale=0.01)
+    with native.Renderer(0) as r:
+        coarse = native.load_network_from_dir(r, 0, root / "coarse")
+        fine = native.load_network_from_dir(r, 1, root / "fine")
+        cam = native.camera_from_samples(samples, 96, 96, 64)
+        for crop, nf in (((0, 0, 96, 96), 128), ((3, 5, 61, 7), 128), ((10, 10, 37, 3), 50)):
+            ref = native.render_image(coarse, fine, cam, nf, seed=2, crop=crop)
+            img, st = native.render_image(coarse, fine, cam, nf, seed=2, crop=crop, skip_dead=True, return_stats=True)
+            assert np.array_equal(img, ref), crop
+            assert st.n_exec_colour > 0.9 * st.n_exec_fine_trunk and st.n_exec_fine_trunk > 0.9 * st.n_fine_points, st
+        co = native.render_image(coarse, fine, cam, 0, seed=2, coarse_only=True, skip_dead=True)
+        assert np.array_equal(co, native.render_image(coarse, fine, cam, 0, seed=2, coarse_only=True))
 
 
 def _coarse_sigmas(native, renderer_net, cam, rdr, x0, y0, w, h, nc, seed, dtype):

@@ -123,6 +123,9 @@ def test_bench_self_launches_two_ranks_on_this_gpu():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["ranks"] == 2 and d["backend"].startswith("gloo") and "REHEARSAL" in d["backend"]
     assert d["value"] > 0 and d["scaling"] == "strong" and d["config"]["rays_per_step"] == 96 * 80
+    pr = d["per_rank"]                                 # attribution of the step: render vs gather, per rank (max / min over ranks)
+    assert len(pr["ms_render"]["by_rank"]) == 2 and pr["ms_render"]["min"] > 0 and pr["ms_gather"]["max"] > 0
+    assert pr["ms_render"]["max"] + pr["ms_gather"]["max"] <= 1.5 * d["ms_per_step"] + 50   # the marks bracket the step's own work
 
 
 def test_bench_rccl_paths_at_world_size_one():
@@ -140,3 +143,4 @@ def test_bench_rccl_paths_at_world_size_one():
         assert p.returncode == 0, p.stderr[-2000:]
         d = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][0])
         assert d["ranks"] == 1 and d["backend"].startswith("nccl") and d["value"] > 0
+        assert d["per_rank"]["ms_gather"]["max"] > 0 and d["per_rank"]["ms_dominant_kernel_per_launch"]["max"] > 0   # HIP events around RCCL's all-gather

@@ -27,7 +27,8 @@ def test_abi_exports_every_declared_symbol(native):
         assert hasattr(L, name), f"{name} declared in the header but not exported"
         assert name in _lib.PROTOTYPES, f"{name} has no ctypes prototype"
     assert set(_lib.PROTOTYPES) == declared
-    assert native.load_library().nerf_abi_version() == 2
+    assert native.load_library().nerf_abi_version() == 3
+    assert native.load_library().nerf_build_variant() == b""      # the product build; variants carry a tag and are refused by the loader
 
 
 def test_no_device_means_loud_failure(native):
@@ -452,7 +453,7 @@ def test_struct_sizes_match_the_library(native):
     L = native.load_library()
     a, b, c = C.c_size_t(), C.c_size_t(), C.c_size_t()
     L.nerf_abi_struct_sizes(C.byref(a), C.byref(b), C.byref(c))
-    assert (a.value, b.value, c.value) == (C.sizeof(_lib.CCamera), C.sizeof(_lib.COpts), C.sizeof(_lib.CStats)) == (60, 56, 104)
+    assert (a.value, b.value, c.value) == (C.sizeof(_lib.CCamera), C.sizeof(_lib.COpts), C.sizeof(_lib.CStats)) == (60, 56, 112)
 
 
 def test_loader_rejects_a_directory_named_like_a_tensor(native, tmp_path):
@@ -475,3 +476,20 @@ def test_render_opts_mirror_maps_every_field(native):
                    "seed": (1 << 40) + 7, "mlp_dtype": 3, "skip_empty": 1, "skip_dead": 1, "hybrid_sampling": 1}
     z = RenderOpts().to_c()
     assert (z.n_coarse, z.n_fine, z.mlp_dtype, z.skip_empty, z.skip_dead, z.hybrid_sampling, z.crop_w, z.ssaa) == (64, 128, 0, 0, 0, 0, 0, 1)
+
+
+def test_loader_refuses_a_variant_build(native, tmp_path):
+    """`make variant` libraries (tuning switches, timing-only diagnostics that make results WRONG on purpose) report a build tag;
+    the loader only accepts them with NERF_ALLOW_VARIANT=1, so NERF_MI355X_LIB cannot silently replace the product library."""
+    import subprocess
+    import sys
+    src = tmp_path / "fake.c"
+    names = "\n".join(f"void {n}(void) {{}}" for n in native._lib.PROTOTYPES if n != "nerf_build_variant")
+    src.write_text(names + '\nconst char *nerf_build_variant(void) { return "probe: -DNERF_DIAG_NO_DMA=1"; }\n')
+    so = tmp_path / "libfake.so"
+    subprocess.check_call(["gcc", "-shared", "-fPIC", "-o", str(so), str(src)])
+    code = "import nerf_rs_amd; nerf_rs_amd.load_library()"
+    env = dict(os.environ, NERF_MI355X_LIB=str(so), PYTHONPATH=ROOT)
+    env.pop("NERF_ALLOW_VARIANT", None)
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env)
+    assert p.returncode != 0 and "tuning variant (probe: -DNERF_DIAG_NO_DMA=1)" in p.stderr

@@ -2,6 +2,7 @@
 """Quick A/B: render the 800x800 frame a few times with the library named by NERF_MI355X_LIB and print the
 device times (ms) of the coarse / fine MLP kernels plus a parity check against the committed C3 crop."""
 import os, sys
+os.environ.setdefault("NERF_ALLOW_VARIANT", "1")  # these tools exist to time variant builds
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
