@@ -37,7 +37,11 @@ typedef short s16x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 #ifndef NERF_BV3_AHEAD
-#define NERF_BV3_AHEAD 4 // A-operand prefetch distance in pieces (even)
+#define NERF_BV3_AHEAD 8 // A-operand prefetch distance in pieces (even, < NERF_BV3_RING - 1, and <= 8: a piece of the NEXT chunk may only be read
+                         // behind the mid-chunk sync that proves it landed).  Measured, full kernel: 2 -> 103.1 ms, 4 -> 104.2, 6 -> 100.0, 8 -> 96.9
+#endif
+#ifndef NERF_BV3_RING
+#define NERF_BV3_RING 16 // register ring of prefetched A operands (8 or 16: must divide the 16 pieces of a chunk)
 #endif
 #ifndef NERF_BV3_SCHED_BARRIER
 #define NERF_BV3_SCHED_BARRIER 1
@@ -77,7 +81,7 @@ struct PipeV {
     const LDS_AS char *rd_base;
     const LDS_AS char *ring_lane;
     uint32_t rd_slot_off;
-    u32x4 a[8];
+    u32x4 a[NERF_BV3_RING];
     uint32_t ring_addr, wr_slot_off, next_off, stream_bytes;
     const char *gbase, *cur_src;
     uint32_t cur_dst, lane16;
@@ -125,19 +129,21 @@ __device__ __forceinline__ bf16x8 pipe_take(PipeV &P) {
 #endif
     static_assert(kAhead % 2 == 0, "paired reads need an even prefetch distance");
     if constexpr ((PH & 1) == 0) {
-        asm volatile("" : "+v"(P.a[PH % 8]), "+v"(P.a[(PH + 1) % 8])); // one s_waitcnt for the pair
-        const u32x4 a = P.a[PH % 8];
-        if constexpr (PH + kAhead == 16) {
+        constexpr int R = NERF_BV3_RING;
+        static_assert((R == 8 || R == 16) && kAhead + 1 < R && kAhead <= 8, "ring");
+        asm volatile("" : "+v"(P.a[PH % R]), "+v"(P.a[(PH + 1) % R])); // one s_waitcnt for the pair
+        const u32x4 a = P.a[PH % R];
+        if constexpr (PH + kAhead == 16) { // the pair to prefetch opens the next chunk (kAhead <= 14: exactly one even phase per chunk does)
             uint32_t off = P.rd_slot_off + kCB;
             off = (off == kRS * kCB) ? 0u : off;
             P.rd_slot_off = off;
             P.rd_base = P.ring_lane + off;
         }
-        P.a[(PH + kAhead) % 8] = *(const LDS_AS u32x4 *)(P.rd_base + ((PH + kAhead) % 16) * 1024);
-        P.a[(PH + kAhead + 1) % 8] = *(const LDS_AS u32x4 *)(P.rd_base + ((PH + kAhead + 1) % 16) * 1024);
+        P.a[(PH + kAhead) % R] = *(const LDS_AS u32x4 *)(P.rd_base + ((PH + kAhead) % 16) * 1024);
+        P.a[(PH + kAhead + 1) % R] = *(const LDS_AS u32x4 *)(P.rd_base + ((PH + kAhead + 1) % 16) * 1024);
         return __builtin_bit_cast(bf16x8, a);
     } else {
-        return __builtin_bit_cast(bf16x8, P.a[PH % 8]);
+        return __builtin_bit_cast(bf16x8, P.a[PH % NERF_BV3_RING]);
     }
 }
 

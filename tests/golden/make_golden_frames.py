@@ -10,6 +10,10 @@ this size (the GPU box has no /root/reference and the -m gpu suite must stay sho
                              cpu_seed1_vs_A            the oracle's seed-1 frame (the jitter noise floor, ~40 dB)
                              cpu_ssaa2_seed1_vs_A      the oracle's seed-1 frame at BASELINE config C5's geometry (800x800 output,
                                                        2x2 rays per pixel = 1600x1600 = 2 560 000 rays, box filter)
+                           and of the north star's last clause ("PSNR within 0.1 dB of CPU output.ppm"), part `ppm512`:
+                             cpu_pi8_512_seed{0,1}_vs_output_ppm_psnr8   8-bit PSNR of the oracle's whole 512x512 frame -- the geometry of the
+                                                       reference's own output.ppm: half field of view pi/8 -- against that file
+                                                       (tests/golden/reference/output.ppm); the GPU frame must land within 0.1 dB of it
 Same chain of trust as make_golden.py: the oracle's MLP is pinned by the reference's 120 golden scalars; the frame is the
 oracle's line-by-line restatement of render_image (src/lib.rs:474-565) with the seeded counter RNG.
 """
@@ -83,6 +87,20 @@ def main():
         gates["cpu_ssaa2_seed1_vs_A"] = psnr(c, a)
         json.dump(gates, open(gates_path, "w"), indent=1)
         print("ssaa2 seed 1:", gates["cpu_ssaa2_seed1_vs_A"], "total %.0f s" % (time.time() - t0), flush=True)
+    if "ppm512" in parts:
+        import math
+        raw = open(os.path.join(committed, "reference", "output.ppm"), "rb").read()
+        magic, dims, maxv, data = raw.split(b"\n", 3)
+        assert magic == b"P6" and dims == b"512 512" and maxv == b"255"
+        ref = np.frombuffer(data, np.uint8).reshape(512, 512, 3).astype(np.float64)
+        cam512 = O.camera_from_samples(S, 512, 512)
+        cam512.alpha_width = cam512.alpha_height = math.pi / 8
+        for seed in (0, 1):
+            img = O.render_image(co, fi, cam512, O.make_opts(64, 128, seed=seed, threads=threads))
+            q = O.quantize_rgb8(img).reshape(512, 512, 3).astype(np.float64)
+            gates[f"cpu_pi8_512_seed{seed}_vs_output_ppm_psnr8"] = 10.0 * math.log10(255.0 ** 2 / float(np.mean((q - ref) ** 2)))
+            json.dump(gates, open(gates_path, "w"), indent=1)
+            print(f"512x512 pi/8 seed {seed} vs output.ppm:", gates[f"cpu_pi8_512_seed{seed}_vs_output_ppm_psnr8"], "total %.0f s" % (time.time() - t0), flush=True)
 
 
 if __name__ == "__main__":

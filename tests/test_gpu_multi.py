@@ -60,6 +60,10 @@ def test_multi_with_skip_dead_and_hybrid_sampling(native, renderer, samples, thr
     one = native.render_image(renderer.coarse, renderer.fine, cam, 128, **kw)
     for n, gather in ((2, "host"), (3, "peer")):
         assert np.array_equal(native.render_image_multi(three[:n], cam, 128, gather=gather, **kw), one)
+    # the f32 skip_dead kernel (in-LDS compaction, in-kernel colour passes) through bands: the same bits as the plain single-context frame
+    plain = native.render_image(renderer.coarse, renderer.fine, cam, 128, seed=0, crop=crop)
+    for n, gather in ((2, "rccl"), (3, "host")):
+        assert np.array_equal(native.render_image_multi(three[:n], cam, 128, gather=gather, seed=0, crop=crop, skip_dead=True), plain)
 
 
 def test_multi_whole_frame_three_contexts(native, renderer, samples, three):
@@ -84,6 +88,33 @@ def test_multi_rccl_gather(native, renderer, samples, three):
         one = native.render_image(renderer.coarse, renderer.fine, cam, 128, seed=0, crop=c)
         assert np.array_equal(native.render_image_multi(three[:n], cam, 128, gather="rccl", seed=0, crop=c), one)
     native.load_library().nerf_multi_release()
+
+
+def test_multi_distinct_devices_when_the_box_has_them(native, renderer, samples):
+    """On a node with >= 2 GPUs (the driver's scaling node; this suite's usual box has one and skips): one context per device, ragged
+    and even bands, every gather -- RCCL proper (ncclCommInitAll + grouped in-place ncclAllGather over distinct devices), xGMI peer
+    copies, host -- must reproduce the single-context frame bit for bit."""
+    import ctypes as C
+    n_dev = C.c_int(0)
+    hip = C.CDLL("libamdhip64.so")
+    assert hip.hipGetDeviceCount(C.byref(n_dev)) == 0
+    if n_dev.value < 2:
+        pytest.skip(f"needs >= 2 GPUs, this box has {n_dev.value}")
+    n = min(n_dev.value, 8)
+    rs = [native.Renderer(i) for i in range(n)]
+    try:
+        for r in rs:
+            r.load_scene(SCENE)
+        cam = native.camera_from_samples(samples, 800, 800, 64)
+        for crop in ((200, 300, 400, 8 * n), (200, 300, 400, 8 * n + 5)):           # even and ragged bands
+            ref = native.render_image(renderer.coarse, renderer.fine, cam, 128, seed=0, crop=crop)
+            for gather in ("rccl", "peer", "host"):
+                assert np.array_equal(native.render_image_multi(rs, cam, 128, gather=gather, seed=0, crop=crop), ref), (crop, gather)
+            assert np.array_equal(native.render_image_multi(rs, cam, 128, gather="rccl", seed=0, crop=crop, skip_dead=True), ref)
+    finally:
+        native.load_library().nerf_multi_release()
+        for r in rs:
+            r.close()
 
 
 def test_multi_argument_errors(native, samples, three):
