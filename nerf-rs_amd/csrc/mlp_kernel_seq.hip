@@ -13,11 +13,12 @@
 //       evaluated (A).  Rays come from a device-side queue (one atomic per ray), so waves that retire rays early take more rays.
 //   COLOUR PASSES on the live samples only, in the same kernel (round 3; rounds 1-2 exported 1 KiB per live sample to HBM for a
 //       second launch: 16.5 GB written + 16.7 GB read per 800x800 frame, several passes per frame to bound that buffer).  The
-//       trunk outputs h8 of the samples with w > 0 are COMPACTED IN LDS: a staging area of 2 x 32 columns x 1 KiB beside the
-//       weight ring; whenever 32 columns are staged the four waves of the workgroup run the colour head on them together,
-//       N-SPLIT: every wave takes all 32 columns (B operands re-read from the staging tile) and a quarter of the output features
-//       (bottleneck: 2 of 8 output tiles, viewdirs: 1 of 4), intermediate activations return to the same staging tile.  The
-//       weight ring switches to the colour part of the stream for the pass and prefetches the trunk's first chunks at its end.
+//       trunk outputs h8 of the samples with w > 0 are COMPACTED IN LDS: a staging ring of 3 x 32 columns x 1 KiB beside the
+//       weight ring; whenever 64 columns are staged the four waves of the workgroup run the colour head on them together,
+//       N-SPLIT: every wave takes all 64 columns (two interleaved groups of 32; B operands re-read from the staging tiles) and a
+//       quarter of the output features (bottleneck: 2 of 8 output tiles, viewdirs: 1 of 4), intermediate activations return to
+//       the same staging tiles.  The weight ring switches to the colour part of the stream for the pass and prefetches the
+//       trunk's first chunks at its end.
 //
 // Every value that reaches a pixel is produced by the same instruction sequence on the same operands as in the fused kernel
 // (an MFMA output tile is a k-ordered fmaf chain per column, independent of the other columns and tiles; LDS round trips are
@@ -67,7 +68,7 @@ __device__ __forceinline__ void pipe_start(Pipe &P, const LDS_AS char *lds, int 
 #ifndef NERF_SEQ_DIAG_STAMP
 #define NERF_SEQ_DIAG_STAMP 0 // k > 0: wave 0 of every workgroup accumulates s_memtime cycles of phase k of the colour passes into the NEXT launch
                               // slot's counters (read back as nerf_stats.n_hybrid_rays = passes, n_exec_coarse_trunk += cycles): 1 whole pass,
-                              // 2 bottleneck loop, 3 viewdirs loop, 4 tail (rgb head), 5 from the vote barrier to the first pass
+                              // 2 bottleneck loop, 3 viewdirs loop, 4 tail (rgb head), 5 from the vote barrier to the first pass, 6 between the two loops
 #endif
 #ifndef NERF_SEQ_DIAG_NO_STAGE
 #define NERF_SEQ_DIAG_NO_STAGE 0 // 1: no staging either (the trunk alone, with the scan)
@@ -90,8 +91,8 @@ namespace {
 
 // ---- the weight ring during colour passes ---------------------------------------------------------------------------------
 // A wave reads a whole chunk's A operands into registers half a chunk ahead, so a chunk's slot is free as soon as every wave
-// has done that: THREE chunks are kept in flight (the trunk keeps two), because a colour chunk lasts only 1 024 cycles per wave
-// (16 MFMAs) against 4 096 in the trunk and the L2 -> LDS latency must still hide behind it.
+// has done that: THREE chunks are kept in flight (the trunk keeps two), because a colour chunk lasts only 2 048 cycles per wave
+// (32 MFMAs) against 4 096 in the trunk and the L2 -> LDS latency must still hide behind it.
 //   start:       issue chunks 0, 1, 2; wait for chunk 0 (vmcnt(8)) + barrier
 //   mid chunk c: wait for chunk c + 1 (vmcnt(4): chunk c + 2 may be in flight) + barrier; read chunk c + 1's operands; issue chunk c + 3
 //                into the slot of chunk c
@@ -380,8 +381,8 @@ __global__ __launch_bounds__(256, 1) void nerf_trunk_seq_kernel(const SeqArgs A)
             li = chunk_scan(W, A, c, sigma, p, h);
         }
         if (EXPORT) {
-            // The four waves' live samples join the staging area in wave order; whenever 32 columns are staged (or a wave's samples
-            // would not fit) the workgroup runs colour passes.  All of this is workgroup-uniform control flow.
+            // The four waves' live samples join the staging ring in wave order; whenever 64 columns are staged (or a wave's samples
+            // would not fit into the 96) the workgroup runs colour passes.  All of this is workgroup-uniform control flow.
             if (running) {
                 if (lane == 0) nlive[wave] = li.n_live;
                 W.live_done += (unsigned)li.n_live;
