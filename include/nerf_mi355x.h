@@ -84,7 +84,8 @@ typedef struct {
     int32_t skip_dead;    /* ext (the rest of it; NERF_MLP_F32, NERF_MLP_BF16X3, NERF_MLP_F16X2): 1 = evaluate only what can reach a pixel.
                            * Rays are walked front to back in chunks of 32 samples; a ray is retired at the reference's
                            * T < 1e-4 cut (src/lib.rs:276-279: every later weight is exactly 0), and the colour head runs only
-                           * on the samples whose weight is > 0 (compacted through HBM, second launch).  EXACT: the image is
+                           * on the samples whose weight is > 0 (F32: compacted in LDS, same launch; split arithmetics: compacted
+                           * through an HBM buffer bounded by NERF_MAX_EXPORT_BYTES, second launch).  EXACT: the image is
                            * bit-identical to skip_dead = 0.  Takes precedence over skip_empty.  Default 0 so that timings are
                            * plain executed-FLOP figures; nerf_stats.n_exec_* report the evaluations actually executed. */
     int32_t hybrid_sampling; /* ext (needs skip_dead = 1, hierarchical render): 1 = run the SAMPLING (coarse) pass in a split
@@ -92,7 +93,7 @@ typedef struct {
                            * the fine pass keeps mlp_dtype), then redo in exact f32 only the rays with an ill-conditioned
                            * hierarchical draw: one whose position is predicted to move by more than 1e-5 in t under the split
                            * arithmetic's density error (|dt| = bin width x |dCDF| / bin mass: light CDF bins, nearly empty rays),
-                           * or whose transmittance passes within 0.1 % of the 1e-4 cut.  Those rays (27 % of the lego frame) get
+                           * or whose transmittance passes within 0.1 % of the 1e-4 cut.  Those rays (a third of the lego frame) get
                            * the f32 path's sample positions bit for bit; the others move by <= 1e-5.  Not bit-identical to
                            * hybrid_sampling = 0 (pixels differ by 2e-8 on average); held to the same Gate 1.
                            * nerf_stats.n_hybrid_rays = rays redone in f32. */
