@@ -469,7 +469,7 @@ def main():
                                                                   (0 if split else dead_stats.n_exec_colour * (N.FLOP_PER_POINT_FULL - N.FLOP_PER_POINT_SIGMA)))
         ach = mfma_per_flop * flops_dom / (ms_dom * 1e-3) / 1e12 if ms_dom > 0 else 0.0
         traffic, traffic_src, traffic_why = pmc_traffic_bytes(
-            (f"void nerf_trunk_seq_kernel_{sfx}<" if split else "void nerf_trunk_seq_kernel<") if args.skip_dead else
+            (f"void nerf_trunk_seq_kernel_{sfx}<true" if split else "void nerf_trunk_seq_kernel<true") if args.skip_dead else
             "void nerf_mlp_kernel_bf16v2<true" if bf16 else "void nerf_mlp_kernel_bf16x3<true" if x3 else
             "void nerf_mlp_kernel_f16x2<true" if x2 else "void nerf_mlp_kernel<true")
         line = {  # noqa: E501
