@@ -94,8 +94,14 @@ int main(int argc, char **argv) {
             st = per[0];
             for (int g = 1; g < gpus; ++g) {
                 st.n_rays += per[g].n_rays;
+                st.n_nonfinite_points += per[g].n_nonfinite_points;
                 if (per[g].ms_total > st.ms_total) { st.ms_total = per[g].ms_total; st.ms_coarse_mlp = per[g].ms_coarse_mlp; st.ms_fine_mlp = per[g].ms_fine_mlp; st.ms_other = per[g].ms_other; }
             }
+        }
+        if (st.n_nonfinite_points) { // a split arithmetic left its range (f16x2: an activation beyond 65 504): the image is wrong there
+            fprintf(stderr, "error: %llu evaluations left the range of the selected arithmetic (nerf_stats.n_nonfinite_points); use --dtype bf16x3 or f32\n",
+                    (unsigned long long)st.n_nonfinite_points);
+            return 1;
         }
         const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         best = secs < best ? secs : best;
