@@ -81,11 +81,11 @@ typedef struct {
                            * evaluation) for every workgroup tile (128 samples in f32, 256 in bf16) whose densities are all 0.
                            * EXACT: such samples have alpha = 0 and weight 0, the image is bit-identical; only the work
                            * changes.  Default 0 so that timings are plain executed-FLOP figures. */
-    int32_t skip_dead;    /* ext (the rest of it; NERF_MLP_F32, NERF_MLP_BF16X3, NERF_MLP_F16X2): 1 = evaluate only what can reach a pixel.
+    int32_t skip_dead;    /* ext (the rest of it; every mlp_dtype): 1 = evaluate only what can reach a pixel.
                            * Rays are walked front to back in chunks of 32 samples; a ray is retired at the reference's
                            * T < 1e-4 cut (src/lib.rs:276-279: every later weight is exactly 0), and the colour head runs only
-                           * on the samples whose weight is > 0 (F32: compacted in LDS, same launch; split arithmetics: compacted
-                           * through an HBM buffer bounded by NERF_MAX_EXPORT_BYTES, second launch).  EXACT: the image is
+                           * on the samples whose weight is > 0 (F32: compacted in LDS, same launch; BF16 and the split arithmetics:
+                           * compacted through an HBM buffer bounded by NERF_MAX_EXPORT_BYTES, second launch).  EXACT: the image is
                            * bit-identical to skip_dead = 0.  Takes precedence over skip_empty.  Default 0 so that timings are
                            * plain executed-FLOP figures; nerf_stats.n_exec_* report the evaluations actually executed. */
     int32_t hybrid_sampling; /* ext (needs skip_dead = 1, hierarchical render): 1 = run the SAMPLING (coarse) pass in a split

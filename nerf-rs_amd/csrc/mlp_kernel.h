@@ -33,6 +33,14 @@ hipError_t nerf_mlp_launch(const MlpArgs &a, bool full, int n_blocks, hipStream_
 // bf16-operand variant (mlp_kernel_bf16v2.hip): a.wstream is the output-tile-major stream (mlp_layout.h kChunks*Bf16V2)
 hipError_t nerf_mlp_bf16v2_init();
 hipError_t nerf_mlp_bf16v2_launch(const MlpArgs &a, bool full, int n_blocks, hipStream_t stream);
+// skip_dead in the bf16 arithmetic (same file): two ray cursors per wave; the trunk exports the bf16-packed relu(h8) of the live samples
+// (512 B per sample; capacity nerf_seq_h8_bytes_bf16) for nerf_colour_bf16_launch.  SeqArgs / ColourArgs are declared below.
+struct SeqArgs;
+struct ColourArgs;
+hipError_t nerf_seq_bf16_init();
+size_t nerf_seq_h8_bytes_bf16(size_t n_samples);
+hipError_t nerf_trunk_seq_bf16_launch(const SeqArgs &a, bool export_live, int n_blocks, hipStream_t stream);
+hipError_t nerf_colour_bf16_launch(const ColourArgs &a, int n_blocks, hipStream_t stream);
 // the same arithmetic on v_mfma_f32_16x16x32_bf16 (mlp_kernel_bf16v3.hip): its own piece contents, the same chunk counts
 hipError_t nerf_mlp_bf16v3_init();
 hipError_t nerf_mlp_bf16v3_launch(const MlpArgs &a, bool full, int n_blocks, hipStream_t stream);
@@ -46,7 +54,8 @@ hipError_t nerf_mlp_bf16x3_launch(const MlpArgs &a, bool full, int n_blocks, hip
 // the cut are never written).  With export_live the colour head runs on every sample with weight > 0:
 //   f32 kernel            in the same launch (live samples compacted in LDS, colour passes of 32 columns): set rgb_out (zero-filled);
 //   split arithmetics     trunk output to `h8` (compacted in HBM, 1 KiB per sample; capacity = all samples of the launch,
-//                         nerf_seq_h8_bytes) for the second launch nerf_colour_*_launch.
+//                         nerf_seq_h8_bytes) for the second launch nerf_colour_*_launch;
+//   bf16                  the same two-launch form with bf16-packed tiles (512 B per sample).
 struct SeqArgs {
     const float *wstream;      // the f32 packed weight stream (sigma part is used)
     const float *small_params;

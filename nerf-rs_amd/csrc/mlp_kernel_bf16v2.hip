@@ -24,6 +24,7 @@
 #include "mlp_common.hip.h"
 #include "mlp_kernel.h"
 #include "mlp_layout.h"
+#include "mlp_seq_common.hip.h"
 
 using namespace nerfmlp;
 using namespace mlpdev;
@@ -526,6 +527,219 @@ __global__ __launch_bounds__(256, 1) void nerf_mlp_kernel_bf16v2(const MlpArgs A
         A.clock_out[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - clk0;
         A.clock_out[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - rt0;
     }
+}
+
+// ---- exact dead-sample skipping in the bf16 arithmetic (skip_dead with mlp_dtype = NERF_MLP_BF16; scheme: mlp_kernel_seq.hip, shared
+// half: mlp_seq_common.hip.h) ---------------------------------------------------------------------------------------------------------
+// A wave's two 32-point sub-tiles are two independent ray cursors: each takes rays from the device-side queue and walks its ray front
+// to back in 32-sample chunks up to the reference's T < 1e-4 cut (src/lib.rs:276-279).  Two launches, as for the split arithmetics:
+// the trunk exports the bf16-PACKED relu(h8) of the live samples (what the bottleneck layer reads: 16 k-steps x 16 B per lane-half =
+// 512 B per sample, half of the f32 tiles' 1 KiB), the colour kernel runs bottleneck + viewdirs + rgb on the compacted slots, 256 per
+// workgroup.  Per column the arithmetic is the fused kernel's (same layers, same stream), so the frame equals the non-skipping bf16 frame
+// bit for bit.
+namespace {
+constexpr int kH8TileBytesBf16 = 16 * 64 * 16; // one 32-sample export tile: [k-step][lane] u32x4 = 16 KiB
+
+__device__ __forceinline__ void pipe_begin(PipeV &P, const LDS_AS char *lds, int lane, int wave, const char *stream, int n_chunks) {
+    P.lane16 = lane * 16;
+    P.ring_lane = lds + P.lane16;
+    P.ring_addr = (uint32_t)(uintptr_t)lds + wave * 4096;
+    P.stream_bytes = n_chunks * kCB;
+    P.gbase = stream + wave * 4096;
+    __syncthreads();
+    pipe_start(P);
+}
+
+template <bool EXPORT>
+__device__ __forceinline__ void chunk_finish_bf16(mlpseq::RayWork &W, const SeqArgs &A, const mlpseq::ChunkIn &c, float sigma, const u32x4 (&Y)[16],
+                                                  int lane, int p, int h) {
+    using namespace mlpseq;
+    const LiveInfo li = chunk_scan(W, A, c, sigma, p, h);
+    if (EXPORT) {
+        if (li.n_live) {
+            unsigned b = 0;
+            if (lane == 0) b = atomicAdd(A.live_count, (unsigned)li.n_live);
+            b = (unsigned)__builtin_amdgcn_readfirstlane((int)b);
+            if (li.live) {
+                const unsigned slot = b + (unsigned)__popcll(li.mask & ((1ull << p) - 1ull));
+                char *dst = (char *)A.h8 + (size_t)(slot >> 5) * kH8TileBytesBf16 + ((slot & 31) + 32 * h) * 16;
+#pragma unroll
+                for (int ks = 0; ks < 16; ++ks) *(u32x4 *)(dst + ks * 1024) = Y[ks];
+                if (h == 0) A.slot_point[slot] = (unsigned)(c.base + c.s);
+            }
+        }
+    }
+    chunk_advance(W, A, c, li.cut, p, h);
+}
+} // namespace
+
+template <bool EXPORT>
+__global__ __launch_bounds__(256, 1) void nerf_trunk_seq_kernel_bf16(const SeqArgs A) {
+    using namespace mlpseq;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const LDS_AS char *lds = (const LDS_AS char *)smem;
+    const LDS_AS float *small = (const LDS_AS float *)(lds + kRS * kCB);
+    LDS_AS int *vote = (LDS_AS int *)(lds + kRS * kCB) + kMiscOff + 8;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int p = lane & 31;
+    const int h = lane >> 5;
+    {
+        float *dst = (float *)(smem + kRS * kCB);
+        for (int i = tid; i < kSmallFloats; i += 256) dst[i] = A.small_params[i];
+    }
+    PipeV P;
+    pipe_begin(P, lds, lane, wave, (const char *)A.wstream, kChunksSigmaBf16V2);
+
+    RayWork W0, W1;
+    work_init(W0, A);
+    work_init(W1, A);
+    for (;;) {
+        work_take(W0, A, lane);
+        work_take(W1, A, lane);
+        if (!work_vote(W0.ray < A.n_rays || W1.ray < A.n_rays, vote, wave, lane)) break;
+        const ChunkIn c0 = chunk_inputs(W0, A, p), c1 = chunk_inputs(W1, A, p);
+        u32x4 E0[4], E1[4];
+        {
+            f32x16 E[2];
+            ENCODE_POINT(c0.px, c0.py, c0.pz, h, E);
+            pack_tile(E[0], E0[0], E0[1]); pack_tile(E[1], E0[2], E0[3]);
+            ENCODE_POINT(c1.px, c1.py, c1.pz, h, E);
+            pack_tile(E[0], E1[0], E1[1]); pack_tile(E[1], E1[2], E1[3]);
+        }
+        u32x4 X0[16], X1[16], Y0[16], Y1[16];
+        Acc C;
+        Heads H;
+        H.alpha[0] = H.alpha[1] = 0.f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) H.rgb[0][c] = H.rgb[1][c] = 0.f;
+        layer<4, 8, true, 0, false, false, 0, true>(E0, E1, X0, X1, C, small + kBiasOff + 0 * 256, small, H, P, h);
+        layer<16, 8, true, 0, true, true, 14, true>(X0, X1, Y0, Y1, C, small + kBiasOff + 1 * 256, small, H, P, h);
+        layer<16, 8, true, 0, true, true, 14, true>(Y0, Y1, X0, X1, C, small + kBiasOff + 2 * 256, small, H, P, h);
+        layer<16, 8, true, 0, true, true, 14, true>(X0, X1, Y0, Y1, C, small + kBiasOff + 3 * 256, small, H, P, h);
+        layer<16, 8, true, 0, true, true, 14, true>(Y0, Y1, X0, X1, C, small + kBiasOff + 4 * 256, small, H, P, h);
+        {
+            u32x4 C0[20], C1[20];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { C0[k] = E0[k]; C1[k] = E1[k]; }
+#pragma unroll
+            for (int k = 0; k < 16; ++k) { C0[4 + k] = X0[k]; C1[4 + k] = X1[k]; }
+            layer<20, 8, true, 0, true, true, 18, true>(C0, C1, Y0, Y1, C, small + kBiasOff + 5 * 256, small, H, P, h);
+        }
+        layer<16, 8, true, 0, true, true, 14, true>(Y0, Y1, X0, X1, C, small + kBiasOff + 6 * 256, small, H, P, h);
+        layer<16, 8, true, EXPORT ? 1 : 2, true, true, 14, false>(X0, X1, Y0, Y1, C, small + kBiasOff + 7 * 256, small, H, P, h);
+        const float s0 = fmaxf(xhalf_sum(H.alpha[0]) + small[kMiscOff + 0], 0.f);
+        const float s1 = fmaxf(xhalf_sum(H.alpha[1]) + small[kMiscOff + 0], 0.f);
+        chunk_finish_bf16<EXPORT>(W0, A, c0, s0, Y0, lane, p, h);
+        chunk_finish_bf16<EXPORT>(W1, A, c1, s1, Y1, lane, p, h);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    work_done(W0, A, lane);
+    work_done(W1, A, lane);
+}
+
+__global__ __launch_bounds__(256, 1) void nerf_colour_kernel_bf16(const ColourArgs A) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const LDS_AS char *lds = (const LDS_AS char *)smem;
+    const LDS_AS float *small = (const LDS_AS float *)(lds + kRS * kCB);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int p = lane & 31;
+    const int h = lane >> 5;
+    {
+        float *dst = (float *)(smem + kRS * kCB);
+        for (int i = tid; i < kSmallFloats; i += 256) dst[i] = A.small_params[i];
+    }
+    PipeV P;
+    pipe_begin(P, lds, lane, wave, (const char *)A.wstream + (size_t)kChunksSigmaBf16V2 * kCB, kChunksFullBf16V2 - kChunksSigmaBf16V2);
+
+    const unsigned n_live = *A.live_count;
+    const int n_tiles = (int)((n_live + (unsigned)kPointsPerBlockBf16V2 - 1u) / (unsigned)kPointsPerBlockBf16V2);
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const unsigned slot0 = (unsigned)tile * kPointsPerBlockBf16V2 + wave * 64 + p, slot1 = slot0 + 32;
+        const bool v0 = slot0 < n_live, v1 = slot1 < n_live;
+        const unsigned i0 = A.slot_point[v0 ? slot0 : n_live - 1], i1 = A.slot_point[v1 ? slot1 : n_live - 1];
+        const float *d0 = A.ray_dirs + 3 * (size_t)(i0 / (unsigned)A.samples_per_ray), *d1 = A.ray_dirs + 3 * (size_t)(i1 / (unsigned)A.samples_per_ray);
+        const float d0x = d0[0], d0y = d0[1], d0z = d0[2], d1x = d1[0], d1y = d1[1], d1z = d1[2];
+        u32x4 X0[16], X1[16], Y0[16], Y1[16];
+        {   // the padding slots of the last tile read whatever the buffer holds (allocated; their columns are never stored)
+            const char *src = (const char *)A.h8 + (size_t)(tile * 8 + wave * 2) * kH8TileBytesBf16 + lane * 16;
+#pragma unroll
+            for (int ks = 0; ks < 16; ++ks) {
+                Y0[ks] = *(const u32x4 *)(src + ks * 1024);
+                Y1[ks] = *(const u32x4 *)(src + kH8TileBytesBf16 + ks * 1024);
+            }
+        }
+        Acc C;
+        Heads H;
+        H.alpha[0] = H.alpha[1] = 0.f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) H.rgb[0][c] = H.rgb[1][c] = 0.f;
+        layer<16, 8, false, 0, false, false, 0, true>(Y0, Y1, X0, X1, C, small + kBiasOff + 8 * 256, small, H, P, h); // bottleneck (src/network.rs:218)
+        u32x4 V0[18], V1[18];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { V0[k] = X0[k]; V1[k] = X1[k]; }
+        {
+            f32x16 D;
+            ENCODE_DIR(d0x, d0y, d0z, h, D); pack_tile(D, V0[16], V0[17]);
+            ENCODE_DIR(d1x, d1y, d1z, h, D); pack_tile(D, V1[16], V1[17]);
+        }
+        layer<18, 4, true, 3, true, false, 14, false>(V0, V1, Y0, Y1, C, small + kBiasViewOff, small, H, P, h); // viewdirs + rgb sums (:220-223)
+        {   // the 8 zero pieces that pad viewdirs to the chunk end
+            bf16x8 d;
+            d = pipe_take<8>(P);                   asm volatile("" ::"v"(d));
+            d = pipe_take<9>(P);  pipe_dma<9>(P);  asm volatile("" ::"v"(d));
+            d = pipe_take<10>(P);                  asm volatile("" ::"v"(d));
+            d = pipe_take<11>(P); pipe_dma<11>(P); asm volatile("" ::"v"(d));
+            d = pipe_take<12>(P);                  asm volatile("" ::"v"(d));
+            d = pipe_take<13>(P); pipe_dma<13>(P); asm volatile("" ::"v"(d));
+            d = pipe_take<14>(P);                  asm volatile("" ::"v"(d));
+            d = pipe_take<15>(P); pipe_dma<15>(P); asm volatile("" ::"v"(d));
+        }
+        float c0[3], c1[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            c0[c] = 1.0f / (1.0f + expf(-(xhalf_sum(H.rgb[0][c]) + small[kMiscOff + 1 + c])));
+            c1[c] = 1.0f / (1.0f + expf(-(xhalf_sum(H.rgb[1][c]) + small[kMiscOff + 1 + c])));
+        }
+        if (h == 0) {
+            if (v0) { A.rgb_out[3 * (size_t)i0] = c0[0]; A.rgb_out[3 * (size_t)i0 + 1] = c0[1]; A.rgb_out[3 * (size_t)i0 + 2] = c0[2]; }
+            if (v1) { A.rgb_out[3 * (size_t)i1] = c1[0]; A.rgb_out[3 * (size_t)i1 + 1] = c1[1]; A.rgb_out[3 * (size_t)i1 + 2] = c1[2]; }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+hipError_t nerf_seq_bf16_init() {
+    const void *ks[3] = {(const void *)nerf_trunk_seq_kernel_bf16<true>, (const void *)nerf_trunk_seq_kernel_bf16<false>, (const void *)nerf_colour_kernel_bf16};
+    for (int i = 0; i < 3; ++i) {
+        hipError_t e = hipFuncSetAttribute(ks[i], hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytesBf16V2);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
+size_t nerf_seq_h8_bytes_bf16(size_t n_samples) { // capacity for n_samples live samples, rounded up to whole colour workgroups (256 slots)
+    const size_t tiles = (n_samples + kPointsPerBlockBf16V2 - 1) / kPointsPerBlockBf16V2 * 8 + 8;
+    return tiles * kH8TileBytesBf16;
+}
+
+hipError_t nerf_trunk_seq_bf16_launch(const SeqArgs &a, bool export_live, int n_blocks, hipStream_t stream) {
+    if (a.n_rays <= 0 || a.samples_per_ray <= 0) return hipSuccess;
+    const long long wg_rays = ((long long)a.n_rays + 7) / 8; // eight ray cursors per workgroup
+    if (n_blocks > wg_rays) n_blocks = (int)wg_rays;
+    if (n_blocks < 1) n_blocks = 1;
+    if (export_live) hipLaunchKernelGGL(nerf_trunk_seq_kernel_bf16<true>, dim3(n_blocks), dim3(256), kLdsBytesBf16V2, stream, a);
+    else hipLaunchKernelGGL(nerf_trunk_seq_kernel_bf16<false>, dim3(n_blocks), dim3(256), kLdsBytesBf16V2, stream, a);
+    return hipGetLastError();
+}
+
+hipError_t nerf_colour_bf16_launch(const ColourArgs &a, int n_blocks, hipStream_t stream) {
+    if (n_blocks < 1) n_blocks = 1;
+    hipLaunchKernelGGL(nerf_colour_kernel_bf16, dim3(n_blocks), dim3(256), kLdsBytesBf16V2, stream, a);
+    return hipGetLastError();
 }
 
 template <bool FULL, int MODE>

@@ -35,7 +35,7 @@ __device__ __forceinline__ void work_init(RayWork &W, const SeqArgs &A) {
 
 // Take the next ray from the device-side queue if the current one is finished, then vote: the four waves of a workgroup walk the
 // weight stream in lockstep, so they leave together once nobody has a ray.  Contains one workgroup barrier.  `vote` = 4 ints of LDS.
-__device__ __forceinline__ bool work_acquire(RayWork &W, const SeqArgs &A, LDS_AS int *vote, int wave, int lane) {
+__device__ __forceinline__ void work_take(RayWork &W, const SeqArgs &A, int lane) {
     if (W.chunk >= W.n_chunks) {
         unsigned r = 0;
         if (lane == 0) r = atomicAdd(A.ray_counter, 1u);
@@ -47,9 +47,17 @@ __device__ __forceinline__ bool work_acquire(RayWork &W, const SeqArgs &A, LDS_A
         W.chunk = 0;
         W.T = 1.0f;
     }
-    if (lane == 0) vote[wave] = W.ray < A.n_rays ? 1 : 0;
+}
+
+__device__ __forceinline__ bool work_vote(bool has_work, LDS_AS int *vote, int wave, int lane) {
+    if (lane == 0) vote[wave] = has_work ? 1 : 0;
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     return (vote[0] | vote[1] | vote[2] | vote[3]) != 0;
+}
+
+__device__ __forceinline__ bool work_acquire(RayWork &W, const SeqArgs &A, LDS_AS int *vote, int wave, int lane) {
+    work_take(W, A, lane);
+    return work_vote(W.ray < A.n_rays, vote, wave, lane);
 }
 
 // Lane p's sample of the chunk: position p = origin + d_hat * t with the multiply and the add rounded separately (src/lib.rs:436).

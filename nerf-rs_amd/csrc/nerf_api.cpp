@@ -344,11 +344,11 @@ int nerfint::render_device(nerf_ctx *c, const nerf_camera *cam, const nerf_rende
                                                 : (split_dtype(dtype) && !o->coarse_only) ? NERF_MLP_F32 : dtype;
     if (o->skip_empty != 0 && o->skip_empty != 1) return fail(c, NERF_ERR_INVALID, "skip_empty must be 0 or 1");
     if (o->skip_dead != 0 && o->skip_dead != 1) return fail(c, NERF_ERR_INVALID, "skip_dead must be 0 or 1");
-    if (o->skip_dead && dtype == NERF_MLP_BF16) return fail(c, NERF_ERR_INVALID, "skip_dead is implemented for NERF_MLP_F32, NERF_MLP_BF16X3 and NERF_MLP_F16X2 only");
     const bool seq = o->skip_dead != 0;
+    if (seq && dtype == NERF_MLP_BF16 && !g_bf16_v2) return fail(c, NERF_ERR_INVALID, "skip_dead with NERF_MLP_BF16 is not part of the NERF_BF16_V3 variant build");
     if (o->hybrid_sampling != 0 && o->hybrid_sampling != 1) return fail(c, NERF_ERR_INVALID, "hybrid_sampling must be 0 or 1");
-    if (o->hybrid_sampling && !(seq && !o->coarse_only))
-        return fail(c, NERF_ERR_INVALID, "hybrid_sampling needs skip_dead = 1 (mlp_dtype F32, BF16X3 or F16X2) and a hierarchical render");
+    if (o->hybrid_sampling && !(seq && !o->coarse_only && dtype != NERF_MLP_BF16)) // bf16 is its own arithmetic: there are no f32 sample positions to protect
+        return fail(c, NERF_ERR_INVALID, "hybrid_sampling needs skip_dead = 1, mlp_dtype F32, BF16X3 or F16X2, and a hierarchical render");
     if (!c->net[NERF_NET_COARSE].loaded) return fail(c, NERF_ERR_STATE, "coarse network not loaded");
     if (!o->coarse_only && !c->net[NERF_NET_FINE].loaded) return fail(c, NERF_ERR_STATE, "fine network not loaded");
     if (dtype == NERF_MLP_F16X2 && (!c->net[o->coarse_only ? NERF_NET_COARSE : NERF_NET_FINE].wstream_x2 ||
@@ -370,9 +370,11 @@ int nerfint::render_device(nerf_ctx *c, const nerf_camera *cam, const nerf_rende
     const int RW = cw * s, RH = ch * s, RX0 = x0 * s, RY0 = y0 * s;
     // a pass must keep rays * samples within int32 (kernel indices) as well as within the configured budget
     size_t pass_cap = std::min<size_t>(c->max_rays_per_pass, (size_t)0x3fffffff / (size_t)M);
-    // skip_dead in a split arithmetic (two launches): the compacted trunk outputs are sized for the worst case (every sample of a pass
-    // live, 1 KiB each).  The f32 kernel compacts in LDS and runs its colour passes in the same launch: no buffer, no extra passes.
-    const bool h8_export = seq && split_dtype(dtype);
+    // skip_dead in a split arithmetic or in bf16 (two launches): the compacted trunk outputs are sized for the worst case (every sample
+    // of a pass live; 1 KiB each as f32 tiles, 512 B as packed bf16).  The f32 kernel compacts in LDS and runs its colour passes in the
+    // same launch: no buffer, no extra passes.
+    const bool h8_export = seq && (split_dtype(dtype) || dtype == NERF_MLP_BF16);
+    const size_t h8_sample_bytes = dtype == NERF_MLP_BF16 ? 512 : 1024;
     // Budget and allocation of that buffer are ONE critical section per process: contexts that share a device (nerf_render_image_multi's
     // worker threads) would otherwise each claim half of the same free memory and fail in hipMalloc.  A context keeps its buffer while
     // later renders fit; a render that needs less than a quarter of it gives it back (shrinks).
@@ -383,15 +385,15 @@ int nerfint::render_device(nerf_ctx *c, const nerf_camera *cam, const nerf_rende
         size_t budget = c->max_export_bytes, free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) // never more than half of what the device can still give (plus what we already hold)
             budget = std::min(budget, (free_b + c->h8_bytes) / 2);
-        const size_t row_bytes = (size_t)RW * M * 1024;
+        const size_t row_bytes = (size_t)RW * M * h8_sample_bytes;
         if (row_bytes > budget) {
             char msg[256];
-            snprintf(msg, sizeof msg, "skip_dead in a split arithmetic exports 1 KiB per sample: one ray row of this render (%d rays x %d samples) needs "
+            snprintf(msg, sizeof msg, "skip_dead in this arithmetic exports %zu B per sample: one ray row of this render (%d rays x %d samples) needs "
                      "%zu MiB, the budget is %zu MiB (NERF_MAX_EXPORT_BYTES, free device memory / 2); render a narrower crop or use NERF_MLP_F32",
-                     RW, M, row_bytes >> 20, budget >> 20);
+                     h8_sample_bytes, RW, M, row_bytes >> 20, budget >> 20);
             return fail(c, NERF_ERR_INVALID, msg);
         }
-        pass_cap = std::min<size_t>(pass_cap, budget / ((size_t)M * 1024));
+        pass_cap = std::min<size_t>(pass_cap, budget / ((size_t)M * h8_sample_bytes));
     }
     if ((size_t)RW > pass_cap && (size_t)RW * M > (size_t)0x3fffffff) return fail(c, NERF_ERR_INVALID, "ray row too wide for one pass");
     const size_t rows_per_pass = std::max<size_t>(1, std::min<size_t>(RH, pass_cap / (size_t)RW));
@@ -412,14 +414,14 @@ int nerfint::render_device(nerf_ctx *c, const nerf_camera *cam, const nerf_rende
         HIP_TRY(c, hipMemsetAsync(c->d_seq, 0, slots * 16, st));
         const size_t pass_samples = rows_per_pass * RW * (size_t)M;
         if (h8_export) {
-            const size_t need = nerf_seq_h8_bytes(pass_samples);
+            const size_t need = dtype == NERF_MLP_BF16 ? nerf_seq_h8_bytes_bf16(pass_samples) : nerf_seq_h8_bytes(pass_samples);
             if (c->d_h8 && need < c->h8_bytes / 4) { // a much smaller render: give the big buffer back
                 HIP_TRY(c, hipDeviceSynchronize());
                 HIP_TRY(c, hipFree(c->d_h8));
                 c->d_h8 = nullptr; c->h8_bytes = 0;
             }
             if ((rc = ensure_bytes(c, (void **)&c->d_h8, &c->h8_bytes, need))) return rc;
-            if ((rc = ensure_bytes(c, (void **)&c->d_slot_point, &c->slot_point_bytes, (pass_samples + 128) * sizeof(unsigned int)))) return rc;
+            if ((rc = ensure_bytes(c, (void **)&c->d_slot_point, &c->slot_point_bytes, (pass_samples + 256) * sizeof(unsigned int)))) return rc;
             h8_lock.unlock();
         }
         if (hybrid && (rc = ensure_bytes(c, (void **)&c->d_flag_list, &c->flag_list_bytes, rows_per_pass * RW * sizeof(unsigned int)))) return rc;
@@ -466,16 +468,18 @@ int nerfint::render_device(nerf_ctx *c, const nerf_camera *cam, const nerf_rende
                 Timed t(c, st, kind_trunk, (uint64_t)n_rays * spr, timing);
                 HIP_TRY(c, dt == NERF_MLP_BF16X3 ? nerf_trunk_seq_x3_launch(q, rgb_out != nullptr, c->n_cus, st)
                            : dt == NERF_MLP_F16X2 ? nerf_trunk_seq_f16x2_launch(q, rgb_out != nullptr, c->n_cus, st)
+                           : dt == NERF_MLP_BF16  ? nerf_trunk_seq_bf16_launch(q, rgb_out != nullptr, c->n_cus, st)
                                                   : nerf_trunk_seq_launch(q, rgb_out != nullptr, c->n_cus, st));
                 t.done(c->last_render);
             }
-            if (rgb_out && split_dtype(dt)) {
+            if (rgb_out && dt != NERF_MLP_F32) {
                 ColourArgs k{};
                 k.wstream = stream_of(net, dt); k.small_params = net.small; k.live_count = ctr + 1; k.h8 = c->d_h8; k.slot_point = c->d_slot_point;
-                k.ray_dirs = c->d_dirs; k.samples_per_ray = spr; k.rgb_out = rgb_out; k.nonfinite = c->d_nonfinite;
+                k.ray_dirs = c->d_dirs; k.samples_per_ray = spr; k.rgb_out = rgb_out; k.nonfinite = split_dtype(dt) ? c->d_nonfinite : nullptr;
                 Timed t(c, st, 4, 0, timing);
                 HIP_TRY(c, dt == NERF_MLP_BF16X3 ? nerf_colour_x3_launch(k, c->n_cus, st)
-                                                  : nerf_colour_f16x2_launch(k, c->n_cus, st));
+                           : dt == NERF_MLP_F16X2 ? nerf_colour_f16x2_launch(k, c->n_cus, st)
+                                                  : nerf_colour_bf16_launch(k, c->n_cus, st));
                 t.done(c->last_render);
             }
             return NERF_OK;
@@ -700,6 +704,7 @@ int nerf_create(int device_id, nerf_ctx **out) try {
 #endif
             if (e1 == hipSuccess) e1 = nerf_mlp_bf16x3_init();
             if (e1 == hipSuccess) e1 = nerf_seq_init();
+            if (e1 == hipSuccess) e1 = nerf_seq_bf16_init();
             if (e1 == hipSuccess) e1 = nerf_seq_x3_init();
             if (e1 == hipSuccess) e1 = nerf_mlp_f16x2_init();
             if (e1 == hipSuccess) e1 = nerf_seq_f16x2_init();

@@ -129,10 +129,46 @@ def test_skip_dead_fuzz_is_bit_exact():
 
 
 def test_skip_dead_argument_errors(renderer, native, samples):
+    """bf16 is its own arithmetic: there are no f32 sample positions for hybrid_sampling to protect."""
     cam = native.camera_from_samples(samples, 64, 64, 64)
     with pytest.raises(native.NerfError) as e:
-        native.render_image(renderer.coarse, renderer.fine, cam, 128, skip_dead=True, dtype="bf16")
-    assert e.value.code == -1 and "NERF_MLP_F32, NERF_MLP_BF16X3 and NERF_MLP_F16X2 only" in e.value.msg
+        native.render_image(renderer.coarse, renderer.fine, cam, 128, skip_dead=True, hybrid_sampling=True, dtype="bf16")
+    assert e.value.code == -1 and "mlp_dtype F32, BF16X3 or F16X2" in e.value.msg
+
+
+def test_skip_dead_in_bf16_arithmetic(renderer, native, samples, monkeypatch):
+    """skip_dead with mlp_dtype = bf16 (BASELINE config C5's arithmetic): every pass ray-sequential in bf16 (two ray cursors per wave),
+    the colour head on the compacted live samples from bf16-packed exported tiles (512 B per sample).  Per MFMA column the arithmetic
+    is the fused bf16 kernel's, and the fused kernel is what tests/test_gpu_bf16*.py hold against the oracle's bf16 emulation: so the
+    gate here is bit-identity with the non-skipping bf16 frame -- whole C3 frame, C5's 2x2 SSAA, ragged sample counts, coarse_only,
+    a one-pixel crop, and a small export budget (more passes)."""
+    r = renderer
+    cam = native.camera_from_samples(samples, 800, 800, 64)
+    for nc, nf, crop, co, ssaa in ((64, 128, (300, 300, 200, 64), False, 1), (40, 50, (380, 360, 40, 24), False, 1), (4, 0, (150, 150, 100, 40), True, 1),
+                                   (64, 0, (200, 200, 300, 100), True, 1), (33, 31, (0, 0, 800, 8), False, 1), (64, 128, (395, 400, 1, 1), False, 1),
+                                   (64, 128, (350, 380, 90, 30), False, 2)):
+        c = native.camera_from_samples(samples, 800, 800, nc)
+        kw = dict(seed=1, crop=crop, coarse_only=co, ssaa=ssaa, dtype="bf16")
+        a = native.render_image(r.coarse, r.fine, c, nf, **kw)
+        b, st = native.render_image(r.coarse, r.fine, c, nf, skip_dead=True, return_stats=True, **kw)
+        assert np.array_equal(a, b), (nc, nf, crop, co, ssaa)
+        assert st.n_mlp_launches == (2 if co else 3) * st.n_passes
+    full_ref = native.render_image(r.coarse, r.fine, cam, 128, seed=0, dtype="bf16")
+    plain = native.render_image(r.coarse, r.fine, cam, 128, seed=0, dtype="bf16", return_stats=True)[1]
+    full, st = native.render_image(r.coarse, r.fine, cam, 128, seed=0, dtype="bf16", skip_dead=True, return_stats=True)
+    assert np.array_equal(full, full_ref)
+    assert st.n_exec_coarse_trunk < 0.85 * st.n_coarse_points and st.n_exec_fine_trunk < 0.98 * st.n_fine_points
+    assert 0 < st.n_exec_colour < 0.2 * st.n_fine_points
+    print(f"\nskip_dead bf16 full frame: {st.n_rays / (st.ms_total * 1e-3):.0f} rays/s ({st.ms_total:.1f} ms, {st.n_passes} passes) vs plain bf16 "
+          f"{plain.n_rays / (plain.ms_total * 1e-3):.0f} rays/s ({plain.ms_total:.1f} ms); coarse trunk {st.n_exec_coarse_trunk / st.n_coarse_points:.4f}, "
+          f"fine trunk {st.n_exec_fine_trunk / st.n_fine_points:.4f}, colour {st.n_exec_colour / st.n_fine_points:.4f}")
+    monkeypatch.setenv("NERF_MAX_EXPORT_BYTES", str(48 << 20))  # 48 MiB: a 200 x 64 crop of 192 samples (1.2 GiB worst case) needs many passes
+    with native.Renderer(0) as r2:
+        r2.load_scene(SCENE)
+        crop = (300, 300, 200, 64)
+        img, st = native.render_image(r2.coarse, r2.fine, cam, 128, seed=0, crop=crop, skip_dead=True, dtype="bf16", return_stats=True)
+        assert st.n_passes > 8
+        assert np.array_equal(img, native.render_image(r2.coarse, r2.fine, cam, 128, seed=0, crop=crop, dtype="bf16"))
 
 
 def test_skip_dead_in_bf16x3_arithmetic(renderer, native, samples):

@@ -24,7 +24,7 @@ with N.Renderer(0) as r:
         kw = dict(seed=int(rng.integers(0, 1 << 30)), crop=(x0, y0, w, h))
         if rng.random() < 0.15: kw["ssaa"] = 2
         if rng.random() < 0.15: kw["coarse_only"] = True
-        dt = str(rng.choice(["f32", "f32", "f32", "f16x2", "bf16x3"]))
+        dt = str(rng.choice(["f32", "f32", "f32", "f16x2", "bf16x3", "bf16"]))
         ref = N.render_image(r.coarse, r.fine, cam, nf, dtype=dt, **kw)
         img = N.render_image(r.coarse, r.fine, cam, nf, dtype=dt, skip_dead=True, **kw)
         n += 1; rays += w * h * kw.get("ssaa", 1) ** 2
