@@ -436,6 +436,26 @@ def main():
                     "rays_per_s": n_r / (ms * 1e-3), "ms_per_step": ms, "n_rays": st.n_rays,
                     "whole_job_fraction_of_bf16_mfma_roofline": n_r / (ms * 1e-3) * N.flop_per_ray(args.coarse, args.fine) / (PEAK_BF16_MFMA_TFLOPS * 1e12),
                     "device_ms": {"total": st.ms_total, "coarse": st.ms_coarse_mlp, "fine": st.ms_fine_mlp, "other": st.ms_other}}
+        # ... and the same frame with exact dead-sample skipping in the bf16 arithmetic (two ray cursors per wave)
+        c5_frame = frame.clone()
+
+        def c5_dead_step(stats=False):
+            return N.render_image(r.coarse, r.fine, cam, args.fine, seed=args.seed, ssaa=2, dtype="bf16", skip_dead=True,
+                                  device_out=frame.data_ptr(), stream=stream, return_stats=stats)
+        c5_dead_step(); c5_dead_step(); torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        for _ in range(3):
+            c5_dead_step()
+        torch.cuda.synchronize(dev)
+        ms = 1e3 * (time.perf_counter() - t1) / 3
+        st = c5_dead_step(stats=True)
+        extra_c5["with_skip_dead"] = {
+            "rays_per_s": n_r / (ms * 1e-3), "ms_per_step": ms, "image_bit_identical_to_the_bf16_frame": bool(torch.equal(frame, c5_frame)),
+            "executed_fraction_coarse_trunk": st.n_exec_coarse_trunk / max(st.n_coarse_points, 1),
+            "executed_fraction_fine_trunk": st.n_exec_fine_trunk / max(st.n_fine_points, 1),
+            "executed_fraction_colour_head": st.n_exec_colour / max(st.n_fine_points, 1),
+            "device_ms": {"total": st.ms_total, "coarse_trunk": st.ms_coarse_mlp, "fine_trunk_plus_colour": st.ms_fine_mlp, "other": st.ms_other,
+                          "passes": st.n_passes}}
         r.kernel_time_query(reset=True)
     # The timed region leaves the frame in HBM (`value` never includes PCIe); the host-pointer entry point additionally pays
     # one D2H copy of the frame (BASELINE.md section 4 counts it on the GPU side): measured here, reported beside `value`.
@@ -456,7 +476,8 @@ def main():
         x3 = args.dtype == "bf16x3"
         x2 = args.dtype == "f16x2"
         split = x3 or x2
-        sfx = "x3" if x3 else "f16x2"  # kernel-name suffixes of the split arithmetics
+        sfx = "x3" if x3 else "f16x2" if x2 else "bf16"  # kernel-name suffixes of the two-launch skip_dead kernels
+        two_launch = split or bf16                         # skip_dead: trunk launch + colour launch on the HBM-compacted live samples
         peak = PEAK_BF16_MFMA_TFLOPS if (bf16 or split) else PEAK_FP32_MFMA_TFLOPS  # the f16 MFMA forms run at the bf16 rate
         mfma_per_flop = 6.0 if x3 else 3.0 if x2 else 1.0  # executed 16-bit MFMA flops per algorithmic f32 flop
         value = n_rays * args.steps * (world if weak else 1) / dt  # whole-job rays/s over all ranks
@@ -464,12 +485,12 @@ def main():
         flops_dom = pts_dom * N.FLOP_PER_POINT_FULL - n_dom * skipped_per_launch * (N.FLOP_PER_POINT_FULL - N.FLOP_PER_POINT_SIGMA)
         if dead_stats is not None:
             # dominant launch = the ray-sequential fine kernel: dense0..7 + alpha on the samples in front of the cut and -- f32: in the same
-            # launch (colour passes on the LDS-compacted live samples); split arithmetics: in a second launch, not priced here -- the colour head
+            # launch (colour passes on the LDS-compacted live samples); bf16 / split arithmetics: in a second launch, not priced here -- the colour head
             flops_dom = (n_dom / max(dead_stats.n_passes, 1)) * (dead_stats.n_exec_fine_trunk * N.FLOP_PER_POINT_SIGMA +
-                                                                  (0 if split else dead_stats.n_exec_colour * (N.FLOP_PER_POINT_FULL - N.FLOP_PER_POINT_SIGMA)))
+                                                                  (0 if two_launch else dead_stats.n_exec_colour * (N.FLOP_PER_POINT_FULL - N.FLOP_PER_POINT_SIGMA)))
         ach = mfma_per_flop * flops_dom / (ms_dom * 1e-3) / 1e12 if ms_dom > 0 else 0.0
         traffic, traffic_src, traffic_why = pmc_traffic_bytes(
-            (f"void nerf_trunk_seq_kernel_{sfx}<true" if split else "void nerf_trunk_seq_kernel<true") if args.skip_dead else
+            (f"void nerf_trunk_seq_kernel_{sfx}<true" if two_launch else "void nerf_trunk_seq_kernel<true") if args.skip_dead else
             "void nerf_mlp_kernel_bf16v2<true" if bf16 else "void nerf_mlp_kernel_bf16x3<true" if x3 else
             "void nerf_mlp_kernel_f16x2<true" if x2 else "void nerf_mlp_kernel<true")
         line = {  # noqa: E501
@@ -503,7 +524,7 @@ def main():
                          "traffic_source": (f"HBM bytes per launch from this round's committed rocprofv3 PMC passes of the same command ({traffic_src}; "
                                             "2 x FETCH_SIZE + WRITE_SIZE in separate --pmc runs; counters cannot be read from inside the run); "
                                             "algorithmic: 20 B/point") if traffic_src else traffic_why,
-                         "kernel": ((f"nerf_trunk_seq_kernel_{sfx}<EXPORT=true> (fine network, ray-sequential trunk; executed flops)" if split else
+                         "kernel": ((f"nerf_trunk_seq_kernel_{sfx}<EXPORT=true> (fine network, ray-sequential trunk; executed flops)" if two_launch else
                                      "nerf_trunk_seq_kernel<EXPORT=true> (fine network, ray-sequential trunk + in-kernel colour passes; executed flops)")
                                     if dead_stats is not None else
                                     ("nerf_mlp_kernel_bf16v2" if bf16 else "nerf_mlp_kernel_bf16x3" if x3 else "nerf_mlp_kernel_f16x2" if x2 else "nerf_mlp_kernel") +
@@ -511,7 +532,7 @@ def main():
                          "launches": n_dom, "avg_launch_ms": ms_dom / max(n_dom, 1),
                          "points_per_launch": pts_dom // max(n_dom, 1),
                          "flop_per_point": N.FLOP_PER_POINT_SIGMA if dead_stats is not None else N.FLOP_PER_POINT_FULL,
-                         "flop_per_live_point_colour_head": (N.FLOP_PER_POINT_FULL - N.FLOP_PER_POINT_SIGMA) if dead_stats is not None and not split else None},
+                         "flop_per_live_point_colour_head": (N.FLOP_PER_POINT_FULL - N.FLOP_PER_POINT_SIGMA) if dead_stats is not None and not two_launch else None},
         }
         if per_rank is not None:
             line["per_rank"] = per_rank  # max/min over ranks: render (HIP events around the band render), gather (events around the collective)
