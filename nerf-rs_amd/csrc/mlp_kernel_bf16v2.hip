@@ -375,6 +375,60 @@ __device__ __forceinline__ void layer(u32x4 (&in0)[KS], u32x4 (&in1)[KS], u32x4 
     }
 }
 
+// dense0 .. dense7 on the packed encodings E* (the sigma part of the stream, 60 chunks); the alpha partial sums land in H.  PACK_H8:
+// also leave the bf16-packed relu(h8) in Y* (the bottleneck layer's input) -- only needed when a colour head follows.
+template <bool PACK_H8>
+__device__ __forceinline__ void trunk_layers(u32x4 (&E0)[4], u32x4 (&E1)[4], u32x4 (&X0)[16], u32x4 (&X1)[16], u32x4 (&Y0)[16], u32x4 (&Y1)[16], Acc &C,
+                                             const LDS_AS float *small, Heads &H, PipeV &P, int h) {
+    layer<4, 8, true, 0, false, false, 0, true>(E0, E1, X0, X1, C, small + kBiasOff + 0 * 256, small, H, P, h);   // dense0 (src/network.rs:204)
+    layer<16, 8, true, 0, true, true, 14, true>(X0, X1, Y0, Y1, C, small + kBiasOff + 1 * 256, small, H, P, h);
+    layer<16, 8, true, 0, true, true, 14, true>(Y0, Y1, X0, X1, C, small + kBiasOff + 2 * 256, small, H, P, h);
+    layer<16, 8, true, 0, true, true, 14, true>(X0, X1, Y0, Y1, C, small + kBiasOff + 3 * 256, small, H, P, h);
+    layer<16, 8, true, 0, true, true, 14, true>(Y0, Y1, X0, X1, C, small + kBiasOff + 4 * 256, small, H, P, h);
+    {   // dense5 on [encoding (4 k-steps) ; h4 (16 k-steps)] (src/network.rs:209-210)
+        u32x4 C0[20], C1[20];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { C0[k] = E0[k]; C1[k] = E1[k]; }
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { C0[4 + k] = X0[k]; C1[4 + k] = X1[k]; }
+        layer<20, 8, true, 0, true, true, 18, true>(C0, C1, Y0, Y1, C, small + kBiasOff + 5 * 256, small, H, P, h); // h4's last tile lands in C*[18], [19]
+    }
+    layer<16, 8, true, 0, true, true, 14, true>(Y0, Y1, X0, X1, C, small + kBiasOff + 6 * 256, small, H, P, h);
+    // dense7: alpha head from the f32 accumulators
+    layer<16, 8, true, PACK_H8 ? 1 : 2, true, true, 14, false>(X0, X1, Y0, Y1, C, small + kBiasOff + 7 * 256, small, H, P, h);
+}
+
+// bottleneck + viewdirs + rgb (the colour part of the stream, 13 chunks) on the packed relu(h8) in Y*: sigmoid colours of both sub-tiles
+__device__ __forceinline__ void colour_layers(u32x4 (&X0)[16], u32x4 (&X1)[16], u32x4 (&Y0)[16], u32x4 (&Y1)[16], Acc &C, const float (&d0)[3],
+                                              const float (&d1)[3], const LDS_AS float *small, Heads &H, PipeV &P, int h, float (&c0)[3], float (&c1)[3]) {
+    layer<16, 8, false, 0, false, false, 0, true>(Y0, Y1, X0, X1, C, small + kBiasOff + 8 * 256, small, H, P, h); // bottleneck: no activation (:218)
+    u32x4 V0[18], V1[18];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { V0[k] = X0[k]; V1[k] = X1[k]; }
+    {
+        f32x16 D;
+        ENCODE_DIR(d0[0], d0[1], d0[2], h, D); pack_tile(D, V0[16], V0[17]);
+        ENCODE_DIR(d1[0], d1[1], d1[2], h, D); pack_tile(D, V1[16], V1[17]);
+    }
+    layer<18, 4, true, 3, true, false, 14, false>(V0, V1, Y0, Y1, C, small + kBiasViewOff, small, H, P, h); // viewdirs + rgb partial sums (:220-223)
+    {   // viewdirs' 72 pieces end at phase 8; the stream carries 8 zero pieces up to the chunk end: step over them
+        bf16x8 d;
+        d = pipe_take<8>(P);                   asm volatile("" ::"v"(d));
+        d = pipe_take<9>(P);  pipe_dma<9>(P);  asm volatile("" ::"v"(d));
+        d = pipe_take<10>(P);                  asm volatile("" ::"v"(d));
+        d = pipe_take<11>(P); pipe_dma<11>(P); asm volatile("" ::"v"(d));
+        d = pipe_take<12>(P);                  asm volatile("" ::"v"(d));
+        d = pipe_take<13>(P); pipe_dma<13>(P); asm volatile("" ::"v"(d));
+        d = pipe_take<14>(P);                  asm volatile("" ::"v"(d));
+        d = pipe_take<15>(P); pipe_dma<15>(P); asm volatile("" ::"v"(d));
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { // sigmoid (src/network.rs:165)
+        c0[c] = 1.0f / (1.0f + expf(-(xhalf_sum(H.rgb[0][c]) + small[kMiscOff + 1 + c])));
+        c1[c] = 1.0f / (1.0f + expf(-(xhalf_sum(H.rgb[1][c]) + small[kMiscOff + 1 + c])));
+    }
+}
+
 } // namespace
 
 template <bool FULL, int MODE>
@@ -452,22 +506,7 @@ __global__ __launch_bounds__(256, 1) void nerf_mlp_kernel_bf16v2(const MlpArgs A
 #pragma unroll
         for (int c = 0; c < 3; ++c) H.rgb[0][c] = H.rgb[1][c] = 0.f;
 
-        layer<4, 8, true, 0, false, false, 0, true>(E0, E1, X0, X1, C, small + kBiasOff + 0 * 256, small, H, P, h);   // dense0 (src/network.rs:204)
-        layer<16, 8, true, 0, true, true, 14, true>(X0, X1, Y0, Y1, C, small + kBiasOff + 1 * 256, small, H, P, h);
-        layer<16, 8, true, 0, true, true, 14, true>(Y0, Y1, X0, X1, C, small + kBiasOff + 2 * 256, small, H, P, h);
-        layer<16, 8, true, 0, true, true, 14, true>(X0, X1, Y0, Y1, C, small + kBiasOff + 3 * 256, small, H, P, h);
-        layer<16, 8, true, 0, true, true, 14, true>(Y0, Y1, X0, X1, C, small + kBiasOff + 4 * 256, small, H, P, h);
-        {   // dense5 on [encoding (4 k-steps) ; h4 (16 k-steps)] (src/network.rs:209-210)
-            u32x4 C0[20], C1[20];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) { C0[k] = E0[k]; C1[k] = E1[k]; }
-#pragma unroll
-            for (int k = 0; k < 16; ++k) { C0[4 + k] = X0[k]; C1[4 + k] = X1[k]; }
-            layer<20, 8, true, 0, true, true, 18, true>(C0, C1, Y0, Y1, C, small + kBiasOff + 5 * 256, small, H, P, h); // h4's last tile lands in C*[18], [19]
-        }
-        layer<16, 8, true, 0, true, true, 14, true>(Y0, Y1, X0, X1, C, small + kBiasOff + 6 * 256, small, H, P, h);
-        // dense7: alpha head from the f32 accumulators; the packed h8 is only needed when the colour branch follows
-        layer<16, 8, true, FULL ? 1 : 2, true, true, 14, false>(X0, X1, Y0, Y1, C, small + kBiasOff + 7 * 256, small, H, P, h);
+        trunk_layers<FULL>(E0, E1, X0, X1, Y0, Y1, C, small, H, P, h);
         const float s0 = fmaxf(xhalf_sum(H.alpha[0]) + small[kMiscOff + 0], 0.f); // ReLU(alpha) (src/network.rs:216)
         const float s1 = fmaxf(xhalf_sum(H.alpha[1]) + small[kMiscOff + 0], 0.f);
         if (h == 0) {
@@ -489,33 +528,9 @@ __global__ __launch_bounds__(256, 1) void nerf_mlp_kernel_bf16v2(const MlpArgs A
                     continue;
                 }
             }
-            layer<16, 8, false, 0, false, false, 0, true>(Y0, Y1, X0, X1, C, small + kBiasOff + 8 * 256, small, H, P, h); // bottleneck: no activation (:218)
-            u32x4 V0[18], V1[18];
-#pragma unroll
-            for (int k = 0; k < 16; ++k) { V0[k] = X0[k]; V1[k] = X1[k]; }
-            {
-                f32x16 D;
-                ENCODE_DIR(in0.dx, in0.dy, in0.dz, h, D); pack_tile(D, V0[16], V0[17]);
-                ENCODE_DIR(in1.dx, in1.dy, in1.dz, h, D); pack_tile(D, V1[16], V1[17]);
-            }
-            layer<18, 4, true, 3, true, false, 14, false>(V0, V1, Y0, Y1, C, small + kBiasViewOff, small, H, P, h); // viewdirs + rgb partial sums (:220-223)
-            {   // viewdirs' 72 pieces end at phase 8; the stream carries 8 zero pieces up to the chunk end: step over them
-                bf16x8 d;
-                d = pipe_take<8>(P);                   asm volatile("" ::"v"(d));
-                d = pipe_take<9>(P);  pipe_dma<9>(P);  asm volatile("" ::"v"(d));
-                d = pipe_take<10>(P);                  asm volatile("" ::"v"(d));
-                d = pipe_take<11>(P); pipe_dma<11>(P); asm volatile("" ::"v"(d));
-                d = pipe_take<12>(P);                  asm volatile("" ::"v"(d));
-                d = pipe_take<13>(P); pipe_dma<13>(P); asm volatile("" ::"v"(d));
-                d = pipe_take<14>(P);                  asm volatile("" ::"v"(d));
-                d = pipe_take<15>(P); pipe_dma<15>(P); asm volatile("" ::"v"(d));
-            }
+            const float d0[3] = {in0.dx, in0.dy, in0.dz}, d1[3] = {in1.dx, in1.dy, in1.dz};
             float c0[3], c1[3];
-#pragma unroll
-            for (int c = 0; c < 3; ++c) { // sigmoid (src/network.rs:165)
-                c0[c] = 1.0f / (1.0f + expf(-(xhalf_sum(H.rgb[0][c]) + small[kMiscOff + 1 + c])));
-                c1[c] = 1.0f / (1.0f + expf(-(xhalf_sum(H.rgb[1][c]) + small[kMiscOff + 1 + c])));
-            }
+            colour_layers(X0, X1, Y0, Y1, C, d0, d1, small, H, P, h, c0, c1);
             if (h == 0) {
                 if (v0) { A.rgb_out[3 * (size_t)i0] = c0[0]; A.rgb_out[3 * (size_t)i0 + 1] = c0[1]; A.rgb_out[3 * (size_t)i0 + 2] = c0[2]; }
                 if (v1) { A.rgb_out[3 * (size_t)i1] = c1[0]; A.rgb_out[3 * (size_t)i1 + 1] = c1[1]; A.rgb_out[3 * (size_t)i1 + 2] = c1[2]; }
@@ -614,21 +629,7 @@ __global__ __launch_bounds__(256, 1) void nerf_trunk_seq_kernel_bf16(const SeqAr
         H.alpha[0] = H.alpha[1] = 0.f;
 #pragma unroll
         for (int c = 0; c < 3; ++c) H.rgb[0][c] = H.rgb[1][c] = 0.f;
-        layer<4, 8, true, 0, false, false, 0, true>(E0, E1, X0, X1, C, small + kBiasOff + 0 * 256, small, H, P, h);
-        layer<16, 8, true, 0, true, true, 14, true>(X0, X1, Y0, Y1, C, small + kBiasOff + 1 * 256, small, H, P, h);
-        layer<16, 8, true, 0, true, true, 14, true>(Y0, Y1, X0, X1, C, small + kBiasOff + 2 * 256, small, H, P, h);
-        layer<16, 8, true, 0, true, true, 14, true>(X0, X1, Y0, Y1, C, small + kBiasOff + 3 * 256, small, H, P, h);
-        layer<16, 8, true, 0, true, true, 14, true>(Y0, Y1, X0, X1, C, small + kBiasOff + 4 * 256, small, H, P, h);
-        {
-            u32x4 C0[20], C1[20];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) { C0[k] = E0[k]; C1[k] = E1[k]; }
-#pragma unroll
-            for (int k = 0; k < 16; ++k) { C0[4 + k] = X0[k]; C1[4 + k] = X1[k]; }
-            layer<20, 8, true, 0, true, true, 18, true>(C0, C1, Y0, Y1, C, small + kBiasOff + 5 * 256, small, H, P, h);
-        }
-        layer<16, 8, true, 0, true, true, 14, true>(Y0, Y1, X0, X1, C, small + kBiasOff + 6 * 256, small, H, P, h);
-        layer<16, 8, true, EXPORT ? 1 : 2, true, true, 14, false>(X0, X1, Y0, Y1, C, small + kBiasOff + 7 * 256, small, H, P, h);
+        trunk_layers<EXPORT>(E0, E1, X0, X1, Y0, Y1, C, small, H, P, h);
         const float s0 = fmaxf(xhalf_sum(H.alpha[0]) + small[kMiscOff + 0], 0.f);
         const float s1 = fmaxf(xhalf_sum(H.alpha[1]) + small[kMiscOff + 0], 0.f);
         chunk_finish_bf16<EXPORT>(W0, A, c0, s0, Y0, lane, p, h);
@@ -677,33 +678,9 @@ __global__ __launch_bounds__(256, 1) void nerf_colour_kernel_bf16(const ColourAr
         H.alpha[0] = H.alpha[1] = 0.f;
 #pragma unroll
         for (int c = 0; c < 3; ++c) H.rgb[0][c] = H.rgb[1][c] = 0.f;
-        layer<16, 8, false, 0, false, false, 0, true>(Y0, Y1, X0, X1, C, small + kBiasOff + 8 * 256, small, H, P, h); // bottleneck (src/network.rs:218)
-        u32x4 V0[18], V1[18];
-#pragma unroll
-        for (int k = 0; k < 16; ++k) { V0[k] = X0[k]; V1[k] = X1[k]; }
-        {
-            f32x16 D;
-            ENCODE_DIR(d0x, d0y, d0z, h, D); pack_tile(D, V0[16], V0[17]);
-            ENCODE_DIR(d1x, d1y, d1z, h, D); pack_tile(D, V1[16], V1[17]);
-        }
-        layer<18, 4, true, 3, true, false, 14, false>(V0, V1, Y0, Y1, C, small + kBiasViewOff, small, H, P, h); // viewdirs + rgb sums (:220-223)
-        {   // the 8 zero pieces that pad viewdirs to the chunk end
-            bf16x8 d;
-            d = pipe_take<8>(P);                   asm volatile("" ::"v"(d));
-            d = pipe_take<9>(P);  pipe_dma<9>(P);  asm volatile("" ::"v"(d));
-            d = pipe_take<10>(P);                  asm volatile("" ::"v"(d));
-            d = pipe_take<11>(P); pipe_dma<11>(P); asm volatile("" ::"v"(d));
-            d = pipe_take<12>(P);                  asm volatile("" ::"v"(d));
-            d = pipe_take<13>(P); pipe_dma<13>(P); asm volatile("" ::"v"(d));
-            d = pipe_take<14>(P);                  asm volatile("" ::"v"(d));
-            d = pipe_take<15>(P); pipe_dma<15>(P); asm volatile("" ::"v"(d));
-        }
+        const float d0v[3] = {d0x, d0y, d0z}, d1v[3] = {d1x, d1y, d1z};
         float c0[3], c1[3];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            c0[c] = 1.0f / (1.0f + expf(-(xhalf_sum(H.rgb[0][c]) + small[kMiscOff + 1 + c])));
-            c1[c] = 1.0f / (1.0f + expf(-(xhalf_sum(H.rgb[1][c]) + small[kMiscOff + 1 + c])));
-        }
+        colour_layers(X0, X1, Y0, Y1, C, d0v, d1v, small, H, P, h, c0, c1);
         if (h == 0) {
             if (v0) { A.rgb_out[3 * (size_t)i0] = c0[0]; A.rgb_out[3 * (size_t)i0 + 1] = c0[1]; A.rgb_out[3 * (size_t)i0 + 2] = c0[2]; }
             if (v1) { A.rgb_out[3 * (size_t)i1] = c1[0]; A.rgb_out[3 * (size_t)i1 + 1] = c1[1]; A.rgb_out[3 * (size_t)i1 + 2] = c1[2]; }

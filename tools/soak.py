@@ -13,7 +13,7 @@ with N.Renderer(0) as r:
     r.load_scene(os.path.join(ROOT, "lego_rust"))
     cam = N.camera_from_samples(os.path.join(ROOT, "lego_rust", "tf_reference_samples.json"), 800, 800, 64)
     modes = [(d, dict(skip_empty=sk)) for d in ("f32", "bf16x3", "f16x2", "bf16") for sk in (False, True)]
-    modes += [(d, dict(skip_dead=True)) for d in ("f32", "bf16x3", "f16x2")]
+    modes += [(d, dict(skip_dead=True)) for d in ("f32", "bf16x3", "f16x2", "bf16")]
     modes += [(d, dict(skip_dead=True, hybrid_sampling=True)) for d in ("f32", "bf16x3", "f16x2")]
     for dtype, kw in modes:
         t0 = time.time()
