@@ -165,7 +165,7 @@ __global__ __launch_bounds__(256) void k_resample(ResampleArgs a) {
     //     cdf_j = (T_1 - T_(j+1) + j 1e-5) / S,   S = T_1 - T_end + m 1e-5 (end = m + 1),   dT_i = -T_i sum_{k<i} delta_k dsigma_k   (first order)
     //     d cdf_j = ((T_(j+1) - cdf_j T_end) X_j - cdf_j T_end (X_end - X_j) - (1 - cdf_j) T_1 X_0) / S,   X_j = sum_{k<=j} delta_k dsigma_k
     // (a sample behind the T < 1e-4 cut has no influence: T is frozen there).  With |dsigma_k| <= e_k every X is bounded by the running
-    // sum of delta_k e_k (L1: no assumption on the signs).  e_k = min(kEpsAbs + kEpsRel sigma_k, kEpsCap) for sigma_k > 0 -- the measured
+    // sum of delta_k e_k (L1: no assumption on the signs; each term also carries the quantisation of T, see below).  e_k = min(kEpsAbs + kEpsRel sigma_k, kEpsCap) for sigma_k > 0 -- the measured
     // f16x2 / bf16x3-vs-f32 density differences of the lego networks (between their p99 and their maximum at every magnitude; an exact
     // zero is exact in every arithmetic: no sample of 110 000 rays had sigma = 0 in one and > 0 in the other).  On top, the sequential
     // f32 sums of the CDF round differently as soon as ANY input differs: kRound ulps of 1.0 relative to cdf_j (measured: <= 3 between
@@ -184,7 +184,11 @@ __global__ __launch_bounds__(256) void k_resample(ResampleArgs a) {
                 if (delta < 0.0f) delta = 0.0f;
                 const float s_i = sg[i];
                 const bool behind_cut = i > 0 && Tn[i - 1] < 1e-4f;
-                v = (s_i > 0.0f && !behind_cut) ? delta * fminf(kEpsAbs + kEpsRel * s_i, kEpsCap) : 0.0f;
+                // ... plus the quantisation of T: `T *= 1 - alpha` multiplies by a factor whose ABSOLUTE error is ulp(alpha) (alpha is
+                // rounded on its own grid), a relative error ulp(alpha) / (1 - alpha) of every later T -- 6e-4 behind a sample that
+                // leaves T ~ 1e-4 (rays that start inside matter: 0.1 per million rays of the fuzz moved by 3e-4 before this term)
+                const float al = 1.0f - expf(-s_i * delta);
+                v = (s_i > 0.0f && !behind_cut) ? delta * fminf(kEpsAbs + kEpsRel * s_i, kEpsCap) + 1.2e-7f * al / fmaxf(1.0f - al, 6e-8f) : 0.0f;
             }
 #pragma unroll
             for (int off = 1; off < 64; off <<= 1) { const float o = __shfl_up(v, off, 64); if (lane >= off) v += o; }
@@ -215,7 +219,15 @@ __global__ __launch_bounds__(256) void k_resample(ResampleArgs a) {
         const float cl = cdf[lo], cu = cdf[lo + 1];
         float denom = cu - cl;
         const float bl = bins[lo], bu = bins[lo + 1];
-        if (flagging) light = light || !((bu - bl) * fmaxf(bnd[lo], bnd[lo + 1]) <= a.flag_tau * denom);
+        if (flagging) {
+            const float b_lo = bnd[lo], b_hi = bnd[lo + 1];
+            light = light || !((bu - bl) * fmaxf(b_lo, b_hi) <= a.flag_tau * denom);
+            // a draw within b of an edge may land in the NEIGHBOURING bin under the other arithmetic: if that bin is light, the part of
+            // the edge's shift spent in it is stretched by its width / mass (found by tools/fuzz_hybrid_flags.py: 0.7 rays per million
+            // sat next to an empty bin and moved by up to 3.6e-2)
+            if (lo > 0 && u - cl <= b_lo) light = light || !((bl - bins[lo - 1]) * b_lo <= a.flag_tau * (cl - cdf[lo - 1]));
+            if (lo + 1 < m && cu - u <= b_hi) light = light || !((bins[lo + 2] - bu) * b_hi <= a.flag_tau * (cdf[lo + 2] - cu));
+        }
         if (!(denom > 1e-6f)) denom = 1e-6f;
         const float tt = (u - cl) / denom;
         mg[nc + s] = bl + (bu - bl) * tt;

@@ -8,6 +8,7 @@ import sys
 import numpy as np
 
 f32 = np.float32
+ROUND_T = 1.0
 
 
 def philox_u(seed, pix, stream, n):
@@ -123,7 +124,12 @@ def model_bound(q, s, eps_a, eps_r, eps_cap, kappa, l2=0.0):
     e = np.where(s > 0, np.minimum(eps_a + eps_r * s, eps_cap), 0.0)
     Tn = np.concatenate([T[:, 1:], q["cutT"][:, None]], axis=1)      # T_(i+1)
     frozen = np.concatenate([np.zeros((R, 1), bool), Tn[:, :-1] == Tn[:, 1:]], axis=1) & (Tn < 1e-4)  # behind the cut
-    de = np.where(frozen, 0.0, delta * e)
+    # T *= (1 - alpha) in f32: alpha is rounded to its own ulp, so the factor (1 - alpha) carries an ABSOLUTE error of up to ulp(alpha)
+    # -- a relative error ulp(alpha) / (1 - alpha) of T, large when a sample is nearly opaque (found by tools/fuzz_hybrid_flags.py:
+    # rays that start inside matter, T_1 ~ 1e-4 quantised to 6e-8)
+    al = q["alpha"].astype(np.float64)
+    rho = np.where(e > 0, 1.2e-7 * al / np.maximum(1 - al, 6e-8), 0.0) * ROUND_T
+    de = np.where(frozen, 0.0, delta * e + rho)
     if l2 > 0:
         X = l2 * np.sqrt(np.cumsum(de * de, axis=1)); Xend = X[:, -1:]
         rest = l2 * np.sqrt(np.maximum(Xend ** 2 - X ** 2, 0)) / l2 * 1.0
