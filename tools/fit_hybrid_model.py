@@ -29,33 +29,34 @@ def philox_u(seed, pix, stream, n):
     return ((x >> np.uint64(9)).astype(np.float32) * f32(1.0 / 8388608.0)).astype(f32)
 
 
-def resample_quantities(t, s, far):
-    """k_resample's arithmetic (f32, reference order) vectorised over rays"""
+def resample_quantities(t, s, far, dt=np.float32):
+    """k_resample's arithmetic (reference order; f32 as in the kernel, or float64 for the math test) vectorised over rays"""
+    t = t.astype(dt); s = s.astype(dt)
     R, nc = t.shape
-    delta = np.concatenate([t[:, 1:] - t[:, :-1], (f32(far) - t[:, -1:])], axis=1).astype(f32)
-    delta = np.maximum(delta, f32(0))
-    alpha = (f32(1) - np.exp(-(s * delta).astype(f32)).astype(f32)).astype(f32)
-    w = np.zeros_like(t); T = np.ones(R, f32); cut = np.zeros(R, bool); near = np.zeros(R, bool)
+    delta = np.concatenate([t[:, 1:] - t[:, :-1], (dt(far) - t[:, -1:])], axis=1).astype(dt)
+    delta = np.maximum(delta, dt(0))
+    alpha = (dt(1) - np.exp(-(s * delta).astype(dt)).astype(dt)).astype(dt)
+    w = np.zeros_like(t); T = np.ones(R, dt); cut = np.zeros(R, bool); near = np.zeros(R, bool)
     Ts = np.zeros_like(t)
     for i in range(nc):
         Ts[:, i] = T
-        w[:, i] = np.where(cut, f32(0), T * alpha[:, i])
-        T = np.where(cut, T, (T * (f32(1) - alpha[:, i])).astype(f32))
-        near |= np.abs(T - f32(1e-4)) < f32(1e-7)
-        cut |= T < f32(1e-4)
+        w[:, i] = np.where(cut, dt(0), T * alpha[:, i])
+        T = np.where(cut, T, (T * (dt(1) - alpha[:, i])).astype(dt))
+        near |= np.abs(T - dt(1e-4)) < dt(1e-7)
+        cut |= T < dt(1e-4)
     m = nc - 2
-    adj = (np.maximum(w[:, 1:nc - 1], f32(0)) + f32(1e-5)).astype(f32)
-    S = np.zeros(R, f32)
+    adj = (np.maximum(w[:, 1:nc - 1], dt(0)) + dt(1e-5)).astype(dt)
+    S = np.zeros(R, dt)
     for i in range(m):
-        S = (S + adj[:, i]).astype(f32)
-    pdf = (adj / S[:, None]).astype(f32)
-    cdf = np.zeros((R, m + 1), f32)
-    c = np.zeros(R, f32)
+        S = (S + adj[:, i]).astype(dt)
+    pdf = (adj / S[:, None]).astype(dt)
+    cdf = np.zeros((R, m + 1), dt)
+    c = np.zeros(R, dt)
     for i in range(m):
-        c = (c + pdf[:, i]).astype(f32)
+        c = (c + pdf[:, i]).astype(dt)
         cdf[:, i + 1] = c
-    cdf[:, m] = f32(1)
-    bins = (f32(0.5) * (t[:, :-1] + t[:, 1:])).astype(f32)
+    cdf[:, m] = dt(1)
+    bins = (dt(0.5) * (t[:, :-1] + t[:, 1:])).astype(dt)
     return dict(delta=delta, alpha=alpha, w=w, T=Ts, near=near, adj=adj, S=S, cdf=cdf, bins=bins, cutT=T)
 
 
@@ -111,7 +112,7 @@ if __name__ == "__main__" and (len(sys.argv) <= 3 or sys.argv[3] != "eval"):
     main()
 
 
-def model_bound(q, s, eps_a, eps_r, eps_cap, kappa, l2=0.0):
+def model_bound(q, s, eps_a, eps_r, eps_cap, kappa, l2=0.0, e=None, round_t=None):
     """Per-bin-edge bound of |d cdf_j|.  The weights telescope: sum_{i<=j} w_i = 1 - T_(j+1), so with the interior samples 1..j in front
     of edge j, P_j = T_1 - T_(j+1) + j 1e-5, S = T_1 - T_end + m 1e-5, cdf_j = P_j / S and, to first order in d sigma,
         dT_i = -T_i sum_{k<i} delta_k dsigma_k
@@ -121,14 +122,15 @@ def model_bound(q, s, eps_a, eps_r, eps_cap, kappa, l2=0.0):
     Plus the rounding noise of the sequential f32 sums: kappa x 6e-8 x cdf_j."""
     delta, w, T, S, cdf = q["delta"], q["w"], q["T"], q["S"], q["cdf"]
     R, nc = s.shape
-    e = np.where(s > 0, np.minimum(eps_a + eps_r * s, eps_cap), 0.0)
+    if e is None:
+        e = np.where(s > 0, np.minimum(eps_a + eps_r * s, eps_cap), 0.0)
     Tn = np.concatenate([T[:, 1:], q["cutT"][:, None]], axis=1)      # T_(i+1)
     frozen = np.concatenate([np.zeros((R, 1), bool), Tn[:, :-1] == Tn[:, 1:]], axis=1) & (Tn < 1e-4)  # behind the cut
     # T *= (1 - alpha) in f32: alpha is rounded to its own ulp, so the factor (1 - alpha) carries an ABSOLUTE error of up to ulp(alpha)
     # -- a relative error ulp(alpha) / (1 - alpha) of T, large when a sample is nearly opaque (found by tools/fuzz_hybrid_flags.py:
     # rays that start inside matter, T_1 ~ 1e-4 quantised to 6e-8)
     al = q["alpha"].astype(np.float64)
-    rho = np.where(e > 0, 1.2e-7 * al / np.maximum(1 - al, 6e-8), 0.0) * ROUND_T
+    rho = np.where(e > 0, 1.2e-7 * al / np.maximum(1 - al, 6e-8), 0.0) * (ROUND_T if round_t is None else round_t)
     de = np.where(frozen, 0.0, delta * e + rho)
     if l2 > 0:
         X = l2 * np.sqrt(np.cumsum(de * de, axis=1)); Xend = X[:, -1:]
