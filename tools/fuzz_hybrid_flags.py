@@ -69,6 +69,31 @@ def fuzz(r, budget, rng_seed, missed=None):
                 unflagged_rays_beyond={"1e-6": int(hist[0]), "3e-6": int(hist[1]), "5e-6": int(hist[2]), "7e-6": int(hist[3]), "1e-5": int(hist[4])})
 
 
+def fuzz_frames(r, budget, rng_seed):
+    """The same at image level: random small frames rendered with exact-f32 sampling (skip_dead) and with hybrid_sampling in every
+    arithmetic; the hybrid frame must be the f32-sampling frame of the same arithmetic within Gate 1's tolerances (max 5e-4, mean 1e-5)."""
+    rng = np.random.default_rng(rng_seed)
+    tot = dict(frames=0, rays=0, worst_max=0.0, worst_mean=0.0, over_1e4=0, over_5e4=0)
+    t_end = time.time() + budget
+    while time.time() < t_end:
+        W = int(rng.choice([32, 48, 64, 96, 128]))
+        nc, nf = [(64, 128), (64, 128), (48, 96), (32, 64), (20, 50), (64, 64), (33, 77)][int(rng.integers(7))]
+        deg, tilt = float(rng.uniform(0, 360)), float(rng.uniform(-25, 25))
+        cam = N.camera_from_pose(_pose(S, deg, tilt), S["hwf"], S["near"], S["far"], W, W, nc)
+        seed = int(rng.integers(0, 1 << 30))
+        for dt in ("f16x2", "bf16x3", "f32"):
+            ref = N.render_image(r.coarse, r.fine, cam, nf, seed=seed, dtype=dt, skip_dead=True)
+            img = N.render_image(r.coarse, r.fine, cam, nf, seed=seed, dtype=dt, skip_dead=True, hybrid_sampling=True)
+            d = np.abs(img - ref)
+            tot["worst_max"] = max(tot["worst_max"], float(d.max())); tot["worst_mean"] = max(tot["worst_mean"], float(d.mean()))
+            tot["over_1e4"] += int((d.max(axis=2) > 1e-4).sum()); tot["over_5e4"] += int((d.max(axis=2) > 5e-4).sum())
+            tot["rays"] += W * W
+            if d.max() > 5e-4:
+                print(f"FRAME: W {W} pose {deg:.1f}/{tilt:.1f} {nc}+{nf} seed {seed} {dt}: max {d.max():.3e} mean {d.mean():.3e}", flush=True)
+        tot["frames"] += 1
+    return tot
+
+
 def acceptable(res):
     return res["worst"] <= 2.5e-5 and res["misses"] <= max(3, 5e-6 * res["rays"])
 
@@ -78,7 +103,9 @@ if __name__ == "__main__":
     with N.Renderer(0) as r:
         r.load_scene(os.path.join(ROOT, "lego_rust"))
         res = fuzz(r, float(sys.argv[1]) if len(sys.argv) > 1 else 60.0, int(sys.argv[2]) if len(sys.argv) > 2 else 1, missed)
-    print(json.dumps(res))
+        print(json.dumps(res))
+        if len(sys.argv) > 3:  # third argument: seconds of the image-level fuzz
+            print(json.dumps(fuzz_frames(r, float(sys.argv[3]), int(sys.argv[2]))))
     if missed:
         os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
         np.save(os.path.join(ROOT, "gpurun_out", "hyb_fuzz_missed.npy"), np.array(missed, dtype=object), allow_pickle=True)
