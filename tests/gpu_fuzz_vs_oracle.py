@@ -1,0 +1,85 @@
+#!/usr/bin/env python3
+"""GPU path against the LIVE CPU oracle on random views: random poses (any azimuth, +-25 degrees tilt), small frames (24..48 pixels a
+side), several sample-count pairs, random seeds; every frame rendered by the oracle (oracle/nerf_oracle.c, the restatement of
+render_image, src/lib.rs:474-565) and by the GPU in f32, f32 + skip_dead, bf16x3 and f16x2.  skip_dead must reproduce the bits of the
+plain f32 frame.  Against the oracle: every frame's MEAN difference within Gate 1 (1e-5); single pixels are counted against Gate 1's
+5e-4 -- hierarchical sampling is ill-conditioned in places, and wherever two f32 evaluations of the network differ in the last bits
+(fmaf chains on the matrix cores vs separate multiply and add on the CPU) a few pixels per million relocate a fine sample and move by
+1e-3..1e-2; tests/cpu_conditioning_probe.py shows the same rate between two CPU arithmetics.  Test infrastructure (lives under tests/:
+it imports oracle/).
+Usage: python tests/gpu_fuzz_vs_oracle.py [seconds] [rng seed]   (exit code 1 if not acceptable(); tests/test_gpu_parity.py runs a short one)"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):  # noqa: E402
+    sys.path.insert(0, p)
+import nerf_rs_amd as N
+import oracle_py as O
+from test_gpu_hybrid_validation import _pose, _oracle_samples
+
+S = O.load_samples(os.path.join(ROOT, "lego_rust", "tf_reference_samples.json"))
+
+
+def psnr(a, b):
+    mse = float(np.mean((np.clip(a, 0, 1).astype(np.float64) - np.clip(b, 0, 1).astype(np.float64)) ** 2))
+    return 200.0 if mse == 0 else 10 * np.log10(1.0 / mse)
+
+
+def fuzz(r, onets, budget, rng_seed, modes=("f32", "skip_dead", "bf16x3", "f16x2")):
+    rng = np.random.default_rng(rng_seed)
+    tot = dict(frames=0, rays=0, pixels_compared=0, mean_violations=0, frames_with_outliers=0, pixels_over_5e4=0, pixels_over_1e4=0,
+               worst_max=0.0, worst_mean=0.0, worst_psnr=200.0, not_bit_identical=0)
+    t_end = time.time() + budget
+    while time.time() < t_end:
+        W, H = int(rng.choice([24, 32, 40, 48])), int(rng.choice([16, 24, 32]))
+        nc, nf = [(64, 128), (48, 96), (32, 64), (20, 50), (64, 64), (33, 77), (16, 0)][int(rng.integers(7))]
+        deg, tilt = float(rng.uniform(0, 360)), float(rng.uniform(-25, 25))
+        seed = int(rng.integers(0, 1 << 30))
+        m = _pose(S, deg, tilt)
+        coarse_only = nf == 0
+        ref = O.render_image(*onets, O.camera_from_samples(_oracle_samples(S, m), W, H), O.make_opts(nc, nf, coarse_only=coarse_only, seed=seed))
+        cam = N.camera_from_pose(m, S["hwf"], S["near"], S["far"], W, H, nc)
+        plain = None
+        for mode in modes:
+            kw = dict(skip_dead=True) if mode == "skip_dead" else dict(dtype=mode)
+            img = N.render_image(r.coarse, r.fine, cam, nf, seed=seed, coarse_only=coarse_only, **kw)
+            if mode == "f32":
+                plain = img
+            if mode == "skip_dead" and plain is not None and not np.array_equal(img, plain):
+                tot["not_bit_identical"] += 1
+            d = np.abs(img - ref)
+            ps = psnr(img, ref)
+            tot["worst_max"] = max(tot["worst_max"], float(d.max())); tot["worst_mean"] = max(tot["worst_mean"], float(d.mean()))
+            tot["worst_psnr"] = min(tot["worst_psnr"], ps)
+            tot["pixels_compared"] += W * H
+            tot["pixels_over_5e4"] += int((d.max(axis=2) > 5e-4).sum()); tot["pixels_over_1e4"] += int((d.max(axis=2) > 1e-4).sum())
+            if d.mean() > 1e-5:
+                tot["mean_violations"] += 1
+            if d.max() > 5e-4:
+                tot["frames_with_outliers"] += 1
+                print(f"OUTLIER: {W}x{H} pose {deg!r}/{tilt!r} {nc}+{nf} seed {seed} {mode}: max {d.max():.3e} mean {d.mean():.3e} psnr {ps:.1f} "
+                      f"({int((d.max(axis=2) > 5e-4).sum())} pixels)", flush=True)
+        tot["frames"] += 1
+        tot["rays"] += W * H
+    return tot
+
+
+def acceptable(res):
+    """mean within Gate 1 on every frame; relocated-sample outliers bounded in number (<= 1e-4 of the pixels) and size; skip_dead exact"""
+    return (res["mean_violations"] == 0 and res["not_bit_identical"] == 0 and res["worst_max"] <= 5e-2 and
+            res["pixels_over_5e4"] <= max(2, 1e-4 * res["pixels_compared"]))
+
+
+if __name__ == "__main__":
+    O.build()
+    onets = (O.Net(os.path.join(ROOT, "lego_rust", "coarse")), O.Net(os.path.join(ROOT, "lego_rust", "fine")))
+    with N.Renderer(0) as r:
+        r.load_scene(os.path.join(ROOT, "lego_rust"))
+        res = fuzz(r, onets, float(sys.argv[1]) if len(sys.argv) > 1 else 60.0, int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+    print(json.dumps(res))
+    sys.exit(0 if acceptable(res) else 1)

@@ -671,3 +671,14 @@ def test_forward_batch_input_domain_and_batch_cap(renderer, native, oracle_nets)
     L = native.load_library()
     rc = L.nerf_forward_batch_device(renderer.handle, 1, 0x1000, 0x1000, (1 << 31) - 300, 0x1000, 0x1000, None)   # never dereferenced
     assert rc == -1 and b"batch too large" in L.nerf_last_error(renderer.handle)
+
+
+def test_random_views_vs_live_oracle_short(renderer, oracle_nets):
+    """tests/gpu_fuzz_vs_oracle.py for a few seconds: random poses (any azimuth, +-25 degrees tilt), frame shapes, sample-count pairs
+    (incl. coarse-only and odd counts) and seeds, each frame rendered by the live oracle and by the GPU in f32, f32 + skip_dead, bf16x3
+    and f16x2: skip_dead bit-identical to f32; every frame's mean within Gate 1; single-pixel outliers (a relocated fine sample where
+    hierarchical sampling is ill-conditioned -- a few per million pixels, CPU-vs-CPU alike: DESIGN section 2) bounded in number."""
+    import gpu_fuzz_vs_oracle as fz
+    res = fz.fuzz(renderer, oracle_nets, 8.0, 20261004)
+    print("\n", res)
+    assert res["frames"] >= 5 and fz.acceptable(res), res
