@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """GPU path against the LIVE CPU oracle on random views: random poses (any azimuth, +-25 degrees tilt), small frames (24..48 pixels a
-side), several sample-count pairs, random seeds; every frame rendered by the oracle (oracle/nerf_oracle.c, the restatement of
+side; a third of them windows of a larger frame, a sixth with 2 x 2 SSAA), several sample-count pairs, random seeds; every frame rendered by the oracle (oracle/nerf_oracle.c, the restatement of
 render_image, src/lib.rs:474-565) and by the GPU in f32, f32 + skip_dead, bf16x3 and f16x2.  skip_dead must reproduce the bits of the
 plain f32 frame.  Against the oracle: every frame's MEAN difference within Gate 1 (1e-5); single pixels are counted against Gate 1's
 5e-4 -- hierarchical sampling is ill-conditioned in places, and wherever two f32 evaluations of the network differ in the last bits
@@ -42,12 +42,22 @@ def fuzz(r, onets, budget, rng_seed, modes=("f32", "skip_dead", "bf16x3", "f16x2
         seed = int(rng.integers(0, 1 << 30))
         m = _pose(S, deg, tilt)
         coarse_only = nf == 0
-        ref = O.render_image(*onets, O.camera_from_samples(_oracle_samples(S, m), W, H), O.make_opts(nc, nf, coarse_only=coarse_only, seed=seed))
-        cam = N.camera_from_pose(m, S["hwf"], S["near"], S["far"], W, H, nc)
+        # a third of the frames: a random window of a larger frame (render_block's rectangle logic); a sixth: 2 x 2 SSAA
+        crop, ssaa, FW, FH = None, 1, W, H
+        k = int(rng.integers(6))
+        if k < 2:
+            FW, FH = W + int(rng.integers(1, 40)), H + int(rng.integers(1, 40))
+            crop = (int(rng.integers(0, FW - W + 1)), int(rng.integers(0, FH - H + 1)), W, H)
+        elif k == 2:
+            ssaa, W, H = 2, max(W // 2, 8), max(H // 2, 8)
+            FW, FH = W, H
+        ref = O.render_image(*onets, O.camera_from_samples(_oracle_samples(S, m), FW, FH),
+                             O.make_opts(nc, nf, coarse_only=coarse_only, crop=crop, ssaa=ssaa, seed=seed))
+        cam = N.camera_from_pose(m, S["hwf"], S["near"], S["far"], FW, FH, nc)
         plain = None
         for mode in modes:
             kw = dict(skip_dead=True) if mode == "skip_dead" else dict(dtype=mode)
-            img = N.render_image(r.coarse, r.fine, cam, nf, seed=seed, coarse_only=coarse_only, **kw)
+            img = N.render_image(r.coarse, r.fine, cam, nf, seed=seed, coarse_only=coarse_only, crop=crop, ssaa=ssaa, **kw)
             if mode == "f32":
                 plain = img
             if mode == "skip_dead" and plain is not None and not np.array_equal(img, plain):
@@ -62,10 +72,10 @@ def fuzz(r, onets, budget, rng_seed, modes=("f32", "skip_dead", "bf16x3", "f16x2
                 tot["mean_violations"] += 1
             if d.max() > 5e-4:
                 tot["frames_with_outliers"] += 1
-                print(f"OUTLIER: {W}x{H} pose {deg!r}/{tilt!r} {nc}+{nf} seed {seed} {mode}: max {d.max():.3e} mean {d.mean():.3e} psnr {ps:.1f} "
+                print(f"OUTLIER: {W}x{H} crop {crop} of {FW}x{FH} ssaa {ssaa} pose {deg!r}/{tilt!r} {nc}+{nf} seed {seed} {mode}: max {d.max():.3e} mean {d.mean():.3e} psnr {ps:.1f} "
                       f"({int((d.max(axis=2) > 5e-4).sum())} pixels)", flush=True)
         tot["frames"] += 1
-        tot["rays"] += W * H
+        tot["rays"] += W * H * ssaa * ssaa
     return tot
 
 
