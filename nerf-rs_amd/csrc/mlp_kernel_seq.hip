@@ -162,8 +162,9 @@ __device__ __forceinline__ void store_tile(LDS_AS char *tile, int lane, int slot
 // One colour pass: bottleneck + viewdirs + rgb (src/network.rs:218-223) on up to 64 staged columns = two GROUPS of 32 (tiles
 // S.head and S.head + 1 of the staging ring; `n_cols` of them are real, the rest is stale LDS whose results are never stored).
 // All four waves; wave w computes output tiles 2w, 2w+1 of the bottleneck and output tile w of viewdirs for ALL columns, the
-// two groups interleaved: every A operand feeds both, and an accumulation chain is never issued back to back with itself (a
-// dependent v_mfma_f32_32x32x2_f32 costs ~92 cycles instead of 64: measured with single-group passes, profiles/r03_seq_colour_pass.md).
+// two groups interleaved: every A operand feeds both, which doubles the MFMAs per chunk -- a chunk carries ~300-500 cycles of fixed
+// cost (mid-chunk wait + barrier, four DMA pieces per wave, operand reads): single-group passes ran at 92 cycles per MFMA, two groups at
+// 73-80 (profiles/r03_seq_colour_pass.md; a dependent MFMA itself issues at 64.00: tools/probes/mfma_chain_probe.hip).
 // Waves 0..2 each compute one colour channel.  On entry chunk 0 of the colour stream has landed (every wave past the barrier that
 // proves it) and chunks 1, 2 are in flight.
 __device__ __forceinline__ void colour_pass(Pipe &P, const Stage &S, int n_cols, bool last_pass, const char *trunk_gbase, const SeqArgs &A,
