@@ -96,8 +96,8 @@ typedef struct {
                            * first order: light CDF bins, nearly empty rays),
                            * or whose transmittance passes within 0.1 % of the 1e-4 cut.  Those rays (18 % of the lego frame) get
                            * the f32 path's sample positions bit for bit; the others move by <= 1e-5 -- a bound under a measured
-                           * model of the arithmetic's density error, not a proof: a fuzz of 91 M rays (tools/fuzz_hybrid_flags.py)
-                           * found 0.9 unflagged rays per million beyond it, none beyond 1.8e-5.  Not bit-identical to
+                           * model of the arithmetic's density error, not a proof: fuzzes of 700 M rays (tools/fuzz_hybrid_flags.py)
+                           * found 0.9 unflagged rays per million beyond it, the largest at 2.8e-5.  Not bit-identical to
                            * hybrid_sampling = 0 (pixels differ by 2e-8 on average); held to the same Gate 1.
                            * nerf_stats.n_hybrid_rays = rays redone in f32. */
 } nerf_render_opts;

@@ -69,6 +69,7 @@ __device__ __forceinline__ void hidden_layer(f32x16 (&in)[8], f32x16 (&out)[8], 
 // `nonfinite` (optional device counter): points whose density pre-activation is NaN / inf.  With NERF_MLP_F16X2 an activation beyond
 // the f16 range splits into (inf, -inf) and turns into NaN in the next layer; fmaxf below would silently return 0 for it.  One v_cmp
 // per tile makes that observable (nerf_stats.n_nonfinite_points; nerf_forward_batch_ex fails with NERF_ERR_STATE).
+constexpr float kUncertainZeroMargin = 4e-5f; // 2 x the absolute part of k_resample's density-error bound (sampling_kernels.hip)
 __device__ __forceinline__ float alpha_head(const f32x16 (&Y)[8], const LDS_AS float *small, int h, unsigned int *nonfinite, bool valid) {
     const LDS_AS f32x4 *w = (const LDS_AS f32x4 *)(small + kAlphaWOff + h * 128);
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
@@ -90,7 +91,11 @@ __device__ __forceinline__ float alpha_head(const f32x16 (&Y)[8], const LDS_AS f
         const unsigned long long bad = __ballot(valid && !(fabsf(pre) <= 3.0e38f)) & 0xffffffffull; // one lane-half per point
         if (bad && (threadIdx.x & 63) == 0) atomicAdd(nonfinite, (unsigned)__popcll(bad));
     }
-    return fmaxf(pre, 0.f);
+    // An "uncertain zero": the density is 0 here, but the pre-activation sits within the split arithmetics' own error of 0, so the f32
+    // kernel may see a tiny positive density where this one sees none.  It is returned as -0.0f: every consumer treats it as 0
+    // (-(-0) delta = 0, alpha = 0, sigma > 0 false), and hybrid sampling's flag (k_resample) gives the sample an error bound instead
+    // of trusting the zero -- a 255 M-ray fuzz found one all-empty ray whose f32 twin had one density of 4e-7 (tools/fuzz_hybrid_flags.py).
+    return (pre <= 0.f && pre > -kUncertainZeroMargin) ? -0.0f : fmaxf(pre, 0.f);
 }
 
 } // namespace

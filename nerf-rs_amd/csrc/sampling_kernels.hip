@@ -167,9 +167,9 @@ __global__ __launch_bounds__(256) void k_resample(ResampleArgs a) {
     // (a sample behind the T < 1e-4 cut has no influence: T is frozen there).  With |dsigma_k| <= e_k every X is bounded by the running
     // sum of delta_k e_k (L1: no assumption on the signs; each term also carries the quantisation of T, see below).  e_k = min(kEpsAbs + kEpsRel sigma_k, kEpsCap) for sigma_k > 0 -- the measured
     // f16x2 / bf16x3-vs-f32 density differences of the lego networks (between their p99 and their maximum at every magnitude; an exact
-    // zero is exact in every arithmetic: no sample of 110 000 rays had sigma = 0 in one and > 0 in the other).  On top, the sequential
-    // f32 sums of the CDF round differently as soon as ANY input differs: kRound ulps of 1.0 relative to cdf_j (measured: <= 3 between
-    // the arithmetics).  A draw in bin [j, j+1) moves by at most width x max(b_j, b_j+1) / mass; above flag_tau the ray is flagged.
+    // zero is exact in every arithmetic unless its pre-activation is within that error of 0: the split kernels mark those as -0.0f).
+    // On top, the sequential f32 sums of the CDF round differently as soon as ANY input differs: kRound ulps of 1.0 relative to cdf_j
+    // (measured: <= 3 between the arithmetics).  A draw in bin [j, j+1) moves by at most width x max(b_j, b_j+1) / mass; above flag_tau the ray is flagged.
     // Against round 2's one |dCDF| per ray: 0.6 x as many flagged rays on the lego views, and over 17 dumped cases (112 000 rays, 5 of
     // them not used for the fit) no unflagged draw moves by more than 4.8e-6 (round 2's model: 8.1e-6 on the same rays).
     constexpr float kEpsAbs = 2e-5f, kEpsRel = 6e-6f, kEpsCap = 2e-4f, kRound = 6.0f * 5.9604645e-8f;
@@ -188,7 +188,10 @@ __global__ __launch_bounds__(256) void k_resample(ResampleArgs a) {
                 // rounded on its own grid), a relative error ulp(alpha) / (1 - alpha) of every later T -- 6e-4 behind a sample that
                 // leaves T ~ 1e-4 (rays that start inside matter: 0.1 per million rays of the fuzz moved by 3e-4 before this term)
                 const float al = 1.0f - expf(-s_i * delta);
-                v = (s_i > 0.0f && !behind_cut) ? delta * fminf(kEpsAbs + kEpsRel * s_i, kEpsCap) + 1.2e-7f * al / fmaxf(1.0f - al, 6e-8f) : 0.0f;
+                // an exact zero carries no error -- unless the split kernels marked it as uncertain (-0.0f: its pre-activation is within
+                // their own error of 0, mlp_split_kernels.hip.h alpha_head)
+                const bool uncertain_zero = __float_as_uint(s_i) == 0x80000000u;
+                v = ((s_i > 0.0f || uncertain_zero) && !behind_cut) ? delta * fminf(kEpsAbs + kEpsRel * s_i, kEpsCap) + 1.2e-7f * al / fmaxf(1.0f - al, 6e-8f) : 0.0f;
             }
 #pragma unroll
             for (int off = 1; off < 64; off <<= 1) { const float o = __shfl_up(v, off, 64); if (lane >= off) v += o; }
@@ -225,8 +228,10 @@ __global__ __launch_bounds__(256) void k_resample(ResampleArgs a) {
             // a draw within b of an edge may land in the NEIGHBOURING bin under the other arithmetic: if that bin is light, the part of
             // the edge's shift spent in it is stretched by its width / mass (found by tools/fuzz_hybrid_flags.py: 0.7 rays per million
             // sat next to an empty bin and moved by up to 3.6e-2)
-            if (lo > 0 && u - cl <= b_lo) light = light || !((bl - bins[lo - 1]) * b_lo <= a.flag_tau * (cl - cdf[lo - 1]));
-            if (lo + 1 < m && cu - u <= b_hi) light = light || !((bins[lo + 2] - bu) * b_hi <= a.flag_tau * (cdf[lo + 2] - cu));
+            // (the proximity test allows the edge four times its bound: a single density error reaches 3 x its e_k, and here one
+            // error decides -- a 255 M-ray fuzz found one draw 3.1 b from an edge that landed in an empty neighbour, 2.8e-2 away)
+            if (lo > 0 && u - cl <= 4.0f * b_lo) light = light || !((bl - bins[lo - 1]) * b_lo <= a.flag_tau * (cl - cdf[lo - 1]));
+            if (lo + 1 < m && cu - u <= 4.0f * b_hi) light = light || !((bins[lo + 2] - bu) * b_hi <= a.flag_tau * (cdf[lo + 2] - cu));
         }
         if (!(denom > 1e-6f)) denom = 1e-6f;
         const float tt = (u - cl) / denom;

@@ -3,8 +3,8 @@
 include/nerf_mi355x.h): random poses, frame sizes, windows, sample counts and seeds of the lego scene; per case the coarse densities in
 f32 and in a split arithmetic, nerf_stage_hybrid_flags on the latter, and the per-draw displacement between the two sets of draws
 (same uniforms).  Reports rays, flagged fraction, real movers, MISSES (unflagged rays with a draw beyond 1e-5) and the largest unflagged
-displacement.  The bound rests on a statistical model of the density error: expect about one miss per million rays, all below 2e-5.
-Usage: fuzz_hybrid_flags.py [seconds] [rng seed]   (exit code 1 if a miss exceeds 2.5e-5 or the miss rate exceeds 5 per million;
+displacement.  The bound rests on a statistical model of the density error: expect about one miss per million rays, all below 3e-5.
+Usage: fuzz_hybrid_flags.py [seconds] [rng seed]   (exit code 1 if a miss exceeds 5e-5 or the miss rate exceeds 5 per million;
 tests/test_gpu_hybrid_validation.py runs a short one)"""
 import json
 import os
@@ -95,7 +95,7 @@ def fuzz_frames(r, budget, rng_seed):
 
 
 def acceptable(res):
-    return res["worst"] <= 2.5e-5 and res["misses"] <= max(3, 5e-6 * res["rays"])
+    return res["worst"] <= 5e-5 and res["misses"] <= max(3, 5e-6 * res["rays"])
 
 
 if __name__ == "__main__":
