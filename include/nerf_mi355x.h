@@ -167,7 +167,9 @@ int nerf_debug_split_f16x2(const float *values, size_t n, uint16_t *parts /* 2 n
  * n is limited to INT32_MAX minus one grid stride of tiles (~2.1e9 points); larger batches return NERF_ERR_INVALID. */
 int nerf_forward_batch(nerf_ctx *ctx, int which, const float *pts_soa /*3 x n*/, const float *dirs_aos /*n x 3*/,
                        size_t n, float *rgb_aos /*n x 3*/, float *sigma /*n*/);
-/* same with an explicit MLP arithmetic (NERF_MLP_F32 / NERF_MLP_BF16 / NERF_MLP_BF16X3 / NERF_MLP_F16X2) */
+/* same with an explicit MLP arithmetic (NERF_MLP_F32 / NERF_MLP_BF16 / NERF_MLP_BF16X3 / NERF_MLP_F16X2).  In the two split
+ * arithmetics a density of 0 whose pre-activation lies within 4e-5 of 0 is returned as -0.0f (an "uncertain zero": the f32
+ * kernel may see a tiny positive density there; numerically it IS 0 -- hybrid_sampling's flag reads the sign). */
 int nerf_forward_batch_ex(nerf_ctx *ctx, int which, int mlp_dtype, const float *pts_soa, const float *dirs_aos, size_t n,
                           float *rgb_aos, float *sigma);
 /* device pointers, asynchronous on `stream` (a hipStream_t passed as void*; NULL = default stream) */
