@@ -4,7 +4,9 @@ include/nerf_mi355x.h): random poses, frame sizes, windows, sample counts and se
 f32 and in a split arithmetic, nerf_stage_hybrid_flags on the latter, and the per-draw displacement between the two sets of draws
 (same uniforms).  Reports rays, flagged fraction, real movers, MISSES (unflagged rays with a draw beyond 1e-5) and the largest unflagged
 displacement.  The bound rests on a statistical model of the density error: expect about one miss per million rays, all below 3e-5.
-Usage: fuzz_hybrid_flags.py [seconds] [rng seed]   (exit code 1 if a miss exceeds 5e-5 or the miss rate exceeds 5 per million;
+NERF_FUZZ_SCENE=<dir with coarse/ and fine/> fuzzes another network with the lego camera path (the flag's constants were measured on
+the lego networks: run this before enabling hybrid_sampling for a different scene).
+Usage: fuzz_hybrid_flags.py [seconds] [rng seed] [seconds of the image-level fuzz]   (exit code 1 if a miss exceeds 5e-5 or the miss rate exceeds 5 per million;
 tests/test_gpu_hybrid_validation.py runs a short one)"""
 import json
 import os
@@ -99,9 +101,10 @@ def acceptable(res):
 
 
 if __name__ == "__main__":
+    scene = os.environ.get("NERF_FUZZ_SCENE", os.path.join(ROOT, "lego_rust"))  # another network in the reference's directory format
     missed = []  # the missed rays themselves, for offline analysis (tools/fit_hybrid_model.py)
     with N.Renderer(0) as r:
-        r.load_scene(os.path.join(ROOT, "lego_rust"))
+        r.load_scene(scene)
         res = fuzz(r, float(sys.argv[1]) if len(sys.argv) > 1 else 60.0, int(sys.argv[2]) if len(sys.argv) > 2 else 1, missed)
         print(json.dumps(res))
         if len(sys.argv) > 3:  # third argument: seconds of the image-level fuzz
