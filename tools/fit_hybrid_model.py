@@ -2,7 +2,11 @@
 """Offline (CPU, numpy) study of hybrid_sampling's flag on the cases dumped by tools/dump_hybrid_cases.py: emulates k_resample's
 quantities from the split arithmetic's densities and compares candidate per-draw displacement bounds with the measured per-draw
 displacements (GPU, split-arithmetic draws vs f32 draws, same uniforms).
-Usage: fit_hybrid_model.py gpurun_out/hyb_cases.npz [arith]"""
+The kernel applies two rules on top of what is emulated here (both found later by tools/fuzz_hybrid_flags.py, neither changes the
+statistics below by more than 0.1 %): a draw within 4 b of a bin edge is also tested against the neighbouring bin's width / mass,
+and a density of 0 that the split kernels marked as uncertain (-0.0f) carries an error bound like a positive one.
+Usage: fit_hybrid_model.py gpurun_out/hyb_cases.npz [arith]            (exploration)
+       fit_hybrid_model.py gpurun_out/hyb_cases.npz arith eval eps_abs eps_rel eps_cap kappa   (flagged fraction, misses, calibration)"""
 import sys
 
 import numpy as np
