@@ -18,7 +18,8 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ void mm32(bf16x8 a, bf16x8 b, f32x16 &c) { asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b)); }
 
-// W = 16: dwordx4 (one instruction per KiB); W = 4: dword (four instructions per KiB, the same bytes)
+// W = 16: dwordx4 (one instruction per KiB); W = 4: dword (four instructions per KiB, the same bytes); W = 0: no LDS-DMA at all --
+// register-staged (global_load_dwordx4 into VGPRs, ds_write_b128 one iteration later)
 template <int W>
 __device__ __forceinline__ void glds(uint32_t lane_off, const char *gsrc, uint32_t dst) {
     uint32_t keep;
@@ -38,7 +39,9 @@ __global__ __launch_bounds__(256, 1) void probe(const char *src, float *sink, un
     f32x16 c0, c1;
     for (int r = 0; r < 16; ++r) { c0[r] = 0.f; c1[r] = 0.f; }
     u32x4 acc = {0, 0, 0, 0};
-    const uint32_t lane_off = lane * (W == 16 ? 16 : 4);
+    u32x4 stage[P > 0 ? P : 1];
+    for (int i = 0; i < (P > 0 ? P : 1); ++i) stage[i] = acc;
+    const uint32_t lane_off = lane * (W == 4 ? 4 : 16);
     const uint32_t ring = (uint32_t)(uintptr_t)lds;
     uint32_t goff = (blockIdx.x * 4 + wave) * 4096u, slot = wave * 1024u;
     __syncthreads();
@@ -47,7 +50,11 @@ __global__ __launch_bounds__(256, 1) void probe(const char *src, float *sink, un
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             if (MF) { mm32(a, b, c0); }
-            if (j < P) {
+            if (W == 0 && j < P) { // register-staged: global_load_dwordx4 -> VGPRs now, ds_write_b128 of it one iteration later
+                if (it > 0) *(u32x4 *)(lds + ((slot + lane * 16u) % 49152u)) = stage[j < P ? j : 0];
+                stage[j < P ? j : 0] = *(const u32x4 *)(src + ((goff & 0x1fffffu) + lane * 16u));
+                goff += 16384u; slot = (slot + 4096u) % 49152u;
+            } else if (j < P) {
                 constexpr int NI = W == 16 ? 1 : 4;
 #pragma unroll
                 for (int q = 0; q < NI; ++q) glds<W>(lane_off, src + ((goff + q * 256u) & 0x1fffffu), ring + ((slot + q * 256u) % 49152u));
@@ -56,10 +63,11 @@ __global__ __launch_bounds__(256, 1) void probe(const char *src, float *sink, un
             if (READS) { const u32x4 v = *(const u32x4 *)(lds + ((slot + j * 4096u + lane * 16u) % 49152u)); acc[0] ^= v[0]; acc[1] ^= v[1]; acc[2] ^= v[2]; acc[3] ^= v[3]; }
             if (MF) { mm32(a, b, c1); }
         }
-        if (P > 0) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        if (P > 0 && W != 0) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    for (int i = 0; i < (P > 0 ? P : 1); ++i) acc[0] ^= stage[i][0] ^ stage[i][3];
     float s = (float)(acc[0] ^ acc[1] ^ acc[2] ^ acc[3]);
     for (int r = 0; r < 16; ++r) s += c0[r] + c1[r];
     if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
@@ -100,6 +108,10 @@ int main() {
     ROW(2, 4, true, false, "16 MFMAs + 4 x dword per piece");
     ROW(2, 16, true, true, "16 MFMAs + 8 ds_read_b128 + dwordx4 pieces");
     ROW(4, 16, true, true, "16 MFMAs + 8 ds_read_b128 + dwordx4 pieces");
+    ROW(1, 0, true, false, "16 MFMAs + register-staged pieces (global_load_dwordx4 + ds_write_b128)");
+    ROW(2, 0, true, false, "16 MFMAs + register-staged pieces (global_load_dwordx4 + ds_write_b128)");
+    ROW(4, 0, true, false, "16 MFMAs + register-staged pieces (global_load_dwordx4 + ds_write_b128)");
+    ROW(8, 0, false, false, "register-staged pieces only (no MFMA)");
     ROW(8, 16, false, false, "dwordx4 pieces only (no MFMA)");
     ROW(8, 4, false, false, "4 x dword per piece only (no MFMA)");
     return 0;
