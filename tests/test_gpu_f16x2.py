@@ -199,3 +199,26 @@ def test_hybrid_sampling(renderer, native, samples):
         with pytest.raises(native.NerfError) as e:
             native.render_image(renderer.coarse, renderer.fine, cam, 128, crop=(0, 0, 8, 8), hybrid_sampling=True, **kw)
         assert e.value.code == -1 and ("hybrid_sampling needs" in e.value.msg or "skip_dead is implemented" in e.value.msg)
+
+
+def test_uncertain_zeros_are_marked(renderer):
+    """A density of 0 in a split arithmetic is exact only if its pre-activation is clear of 0 by more than the arithmetic's own error;
+    otherwise the f32 kernel may see a tiny positive density there (a 255 M-ray fuzz found an all-empty ray whose f32 twin was not, and
+    hybrid_sampling's flag had trusted the zeros).  The split kernels return such zeros as -0.0f (mlp_split_kernels.hip.h alpha_head):
+    every zero whose f32 twin is positive must carry the mark, the mark must be rare, and marked densities are tiny in f32."""
+    rng = np.random.default_rng(11)
+    n = 1 << 22
+    pts = rng.uniform(-1.6, 1.6, size=(3, n)).astype(np.float32)
+    d = rng.normal(size=(n, 3)); d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    for net in (renderer.coarse, renderer.fine):
+        _, s32 = net.forward_batch(pts, d)
+        assert not np.signbit(s32[s32 == 0]).any()                       # the f32 kernel never marks
+        for dt in ("f16x2", "bf16x3"):
+            _, sp = net.forward_batch(pts, d, dtype=dt)
+            zero = sp == 0
+            marked = zero & np.signbit(sp)
+            twins = zero & (s32 > 0)
+            print(f"\n{dt}: zeros {zero.mean():.3f}, marked {marked.sum()}, zeros with a positive f32 twin {twins.sum()} (largest {s32[twins].max() if twins.any() else 0:.2e}); "
+                  f"positive with a zero f32 twin {((sp > 0) & (s32 == 0)).sum()}")
+            assert not (twins & ~marked).any(), float(s32[twins & ~marked].max())
+            assert marked.mean() < 1e-3 and (s32[marked] < 1e-4).all()
