@@ -225,11 +225,10 @@ __global__ __launch_bounds__(256) void k_resample(ResampleArgs a) {
         if (flagging) {
             const float b_lo = bnd[lo], b_hi = bnd[lo + 1];
             light = light || !((bu - bl) * fmaxf(b_lo, b_hi) <= a.flag_tau * denom);
-            // a draw within b of an edge may land in the NEIGHBOURING bin under the other arithmetic: if that bin is light, the part of
-            // the edge's shift spent in it is stretched by its width / mass (found by tools/fuzz_hybrid_flags.py: 0.7 rays per million
-            // sat next to an empty bin and moved by up to 3.6e-2)
-            // (the proximity test allows the edge four times its bound: a single density error reaches 3 x its e_k, and here one
-            // error decides -- a 255 M-ray fuzz found one draw 3.1 b from an edge that landed in an empty neighbour, 2.8e-2 away)
+            // A draw close to an edge may land in the NEIGHBOURING bin under the other arithmetic: if that bin is light, the part of
+            // the edge's shift spent in it is stretched by its width / mass (tools/fuzz_hybrid_flags.py: 0.7 rays per million sat next
+            // to an empty bin and moved by up to 3.6e-2).  "Close" = within four times the edge's bound: one density error decides here
+            // and a single error reaches 3 x its e_k (a 255 M-ray fuzz found a draw 3.1 b from an edge, 2.8e-2 away afterwards).
             if (lo > 0 && u - cl <= 4.0f * b_lo) light = light || !((bl - bins[lo - 1]) * b_lo <= a.flag_tau * (cl - cdf[lo - 1]));
             if (lo + 1 < m && cu - u <= 4.0f * b_hi) light = light || !((bins[lo + 2] - bu) * b_hi <= a.flag_tau * (cdf[lo + 2] - cu));
         }
