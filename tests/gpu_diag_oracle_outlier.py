@@ -9,11 +9,11 @@ import sys
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tools")):
     sys.path.insert(0, p)
 import nerf_rs_amd as N
 import oracle_py as O
-from test_gpu_hybrid_validation import _pose, _oracle_samples
+from scene_utils import pose as _pose, oracle_samples as _oracle_samples
 
 W, H = int(sys.argv[1]), int(sys.argv[2]); deg, tilt = float(sys.argv[3]), float(sys.argv[4]); nc, nf, seed = (int(v) for v in sys.argv[5:8])
 S = O.load_samples(os.path.join(ROOT, "lego_rust", "tf_reference_samples.json"))

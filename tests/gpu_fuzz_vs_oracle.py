@@ -17,11 +17,11 @@ import time
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):  # noqa: E402
+for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tools")):  # noqa: E402
     sys.path.insert(0, p)
 import nerf_rs_amd as N
 import oracle_py as O
-from test_gpu_hybrid_validation import _pose, _oracle_samples
+from scene_utils import pose as _pose, oracle_samples as _oracle_samples
 
 S = O.load_samples(os.path.join(ROOT, "lego_rust", "tf_reference_samples.json"))
 

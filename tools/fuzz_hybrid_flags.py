@@ -17,9 +17,9 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
 import nerf_rs_amd as N
-from test_gpu_hybrid_validation import _pose
+from scene_utils import pose as _pose
 
 S = json.load(open(os.path.join(ROOT, "lego_rust", "tf_reference_samples.json")))
 FAR = float(S["far"])
