@@ -47,6 +47,7 @@ pub struct nerf_render_opts {
     pub skip_empty: i32,
     pub skip_dead: i32,
     pub hybrid_sampling: i32,
+    pub certify_zero: i32,
 }
 
 #[repr(C)]
@@ -149,9 +150,9 @@ pub fn check_layouts() -> Result<(), String> {
     let (mut a, mut b, mut c) = (0usize, 0usize, 0usize);
     unsafe { nerf_abi_struct_sizes(&mut a, &mut b, &mut c) };
     let mine = (std::mem::size_of::<nerf_camera>(), std::mem::size_of::<nerf_render_opts>(), std::mem::size_of::<nerf_stats>());
-    if (a, b, c) == mine && unsafe { nerf_abi_version() } == 3 {
+    if (a, b, c) == mine && unsafe { nerf_abi_version() } == 4 {
         Ok(())
     } else {
-        Err(format!("libnerf_mi355x: ABI {} with struct sizes {:?}, this crate expects ABI 3 with {:?}", unsafe { nerf_abi_version() }, (a, b, c), mine))
+        Err(format!("libnerf_mi355x: ABI {} with struct sizes {:?}, this crate expects ABI 4 with {:?}", unsafe { nerf_abi_version() }, (a, b, c), mine))
     }
 }

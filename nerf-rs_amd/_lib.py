@@ -28,7 +28,7 @@ class CCamera(C.Structure):
 class COpts(C.Structure):
     _fields_ = [("n_coarse", C.c_int32), ("n_fine", C.c_int32), ("coarse_only", C.c_int32),
                 ("crop_x0", C.c_int32), ("crop_y0", C.c_int32), ("crop_w", C.c_int32), ("crop_h", C.c_int32),
-                ("ssaa", C.c_int32), ("seed", C.c_uint64), ("mlp_dtype", C.c_int32), ("skip_empty", C.c_int32), ("skip_dead", C.c_int32), ("hybrid_sampling", C.c_int32)]
+                ("ssaa", C.c_int32), ("seed", C.c_uint64), ("mlp_dtype", C.c_int32), ("skip_empty", C.c_int32), ("skip_dead", C.c_int32), ("hybrid_sampling", C.c_int32), ("certify_zero", C.c_int32)]
 
 
 class CStats(C.Structure):

@@ -217,8 +217,9 @@ def camera_from_pose(c2w, hwf, near, far, width, height, coarse_samples_per_ray=
 
 class RenderOpts:
     def __init__(self, n_coarse=64, n_fine=128, coarse_only=False, crop=None, ssaa=1, seed=0, dtype="f32", skip_empty=False,
-                 skip_dead=False, hybrid_sampling=False):
+                 skip_dead=False, hybrid_sampling=False, certify_zero=False):
         self.hybrid_sampling = bool(hybrid_sampling)
+        self.certify_zero = bool(certify_zero)
         self.n_coarse, self.n_fine, self.coarse_only, self.crop, self.ssaa, self.seed = \
             n_coarse, n_fine, coarse_only, crop, ssaa, seed
         self.dtype = _DTYPES[dtype]
@@ -233,6 +234,7 @@ class RenderOpts:
         o.ssaa, o.seed, o.mlp_dtype, o.skip_empty = self.ssaa, self.seed, self.dtype, int(self.skip_empty)
         o.skip_dead = int(self.skip_dead)
         o.hybrid_sampling = int(self.hybrid_sampling)
+        o.certify_zero = int(self.certify_zero)
         return o
 
     def out_shape(self, cam):
@@ -240,7 +242,8 @@ class RenderOpts:
 
 
 def render_image(coarse, fine, camera, fine_samples_per_ray=128, *, seed=0, coarse_only=False, crop=None, ssaa=1,
-                 dtype="f32", skip_empty=False, skip_dead=False, hybrid_sampling=False, return_stats=False, device_out=None, stream=0):
+                 dtype="f32", skip_empty=False, skip_dead=False, hybrid_sampling=False, certify_zero=False, return_stats=False, device_out=None,
+                 stream=0):
     """render_image (src/lib.rs:474-565) -> (h, w, 3) float32 linear RGB.
 
     coarse/fine: Network objects of one Renderer; camera.samples_per_ray is the coarse sample count.
@@ -249,7 +252,7 @@ def render_image(coarse, fine, camera, fine_samples_per_ray=128, *, seed=0, coar
     R = coarse.renderer
     if fine is not None and fine.renderer is not R:
         raise NerfError(-1, "coarse and fine networks must live in the same Renderer")
-    opts = RenderOpts(camera.samples_per_ray, fine_samples_per_ray, coarse_only, crop, ssaa, seed, dtype, skip_empty, skip_dead, hybrid_sampling)
+    opts = RenderOpts(camera.samples_per_ray, fine_samples_per_ray, coarse_only, crop, ssaa, seed, dtype, skip_empty, skip_dead, hybrid_sampling, certify_zero)
     o = opts.to_c()
     st = CStats()
     if device_out is not None:
@@ -269,7 +272,7 @@ _GATHERS = {"host": 0, "peer": 1, "rccl": 2, 0: 0, 1: 1, 2: 2}
 
 
 def render_image_multi(renderers, camera, fine_samples_per_ray=128, *, gather="host", seed=0, coarse_only=False, crop=None,
-                       ssaa=1, dtype="f32", skip_empty=False, skip_dead=False, hybrid_sampling=False, return_stats=False):
+                       ssaa=1, dtype="f32", skip_empty=False, skip_dead=False, hybrid_sampling=False, certify_zero=False, return_stats=False):
     """render_image fanned out over several Renderers (one per GPU) inside ONE process, through nerf_render_image_multi:
     row bands on per-context host threads + streams, gathered by direct D2H ("host"), GPU-to-GPU peer copies ("peer") or one
     RCCL all-gather ("rccl").  The reference's counterpart is the rayon fan-out + scatter of src/lib.rs:533-557.
@@ -277,7 +280,7 @@ def render_image_multi(renderers, camera, fine_samples_per_ray=128, *, gather="h
     L = _lib.load_library()
     n = len(renderers)
     handles = (C.c_void_p * n)(*[r.handle for r in renderers])
-    opts = RenderOpts(camera.samples_per_ray, fine_samples_per_ray, coarse_only, crop, ssaa, seed, dtype, skip_empty, skip_dead, hybrid_sampling)
+    opts = RenderOpts(camera.samples_per_ray, fine_samples_per_ray, coarse_only, crop, ssaa, seed, dtype, skip_empty, skip_dead, hybrid_sampling, certify_zero)
     o = opts.to_c()
     shape = opts.out_shape(camera)
     if shape[0] <= 0 or shape[1] <= 0:

@@ -181,6 +181,16 @@ __device__ __forceinline__ RawIn load_raw(const Args &A, int tile_idx, int wave,
     using namespace nerfmlp;
     RawIn r;
     int i = tile_idx * kPointsPerBlock + wave * kPointsPerWave + p;
+    if (MODE == 2) { // slot i of a device-side sample list (instantiated for the f32 kernel's MlpArgs only)
+        const int n = (int)*A.point_list_count;
+        r.a = 0.f; r.b = 0.f; r.c = 0.f; r.dx = 0.f; r.dy = 0.f; r.dz = 1.f;
+        if (n <= 0) return r;
+        const unsigned idx = A.point_list[i < n ? i : n - 1];
+        const unsigned ray = idx / (unsigned)A.samples_per_ray;
+        r.a = A.t[idx]; r.b = __builtin_bit_cast(float, idx);
+        r.dx = A.ray_dirs[3 * (size_t)ray]; r.dy = A.ray_dirs[3 * (size_t)ray + 1]; r.dz = A.ray_dirs[3 * (size_t)ray + 2];
+        return r;
+    }
     i = i < A.n_points ? i : A.n_points - 1;
     if (MODE == 0) {
         r.a = A.pts_soa[i]; r.b = A.pts_soa[(size_t)A.n_points + i]; r.c = A.pts_soa[2 * (size_t)A.n_points + i];

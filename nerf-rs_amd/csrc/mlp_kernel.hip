@@ -67,13 +67,14 @@ __global__ __launch_bounds__(256, 1) void nerf_mlp_kernel(const MlpArgs A) {
         P.nx[2 * j + 1] = *(const LDS_AS f32x4 *)(P.rd_base + j * 2048 + 1024);
     }
 
-    const int n_tiles = (A.n_points + kPointsPerBlock - 1) / kPointsPerBlock;
+    const int n_points = MODE == MLP_MODE_LIST ? (int)*A.point_list_count : A.n_points; // list mode: the length lives on the device
+    const int n_tiles = (n_points + kPointsPerBlock - 1) / kPointsPerBlock;
 #if NERF_PREFETCH_INPUTS
     RawIn nxt = load_raw<MODE>(A, blockIdx.x, wave, p);
 #endif
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        const int i = tile * kPointsPerBlock + wave * kPointsPerWave + p;
-        const bool valid = i < A.n_points;
+        const int slot = tile * kPointsPerBlock + wave * kPointsPerWave + p;
+        const bool valid = slot < n_points;
 #if NERF_PREFETCH_INPUTS
         const RawIn in = nxt;
         nxt = load_raw<MODE>(A, tile + gridDim.x, wave, p); // consumed one tile (~250 us) later
@@ -83,6 +84,7 @@ __global__ __launch_bounds__(256, 1) void nerf_mlp_kernel(const MlpArgs A) {
         float px, py, pz;
         point_of<MODE>(A, in, px, py, pz);
         const float dx = in.dx, dy = in.dy, dz = in.dz;
+        const size_t i = MODE == MLP_MODE_LIST ? (size_t)__builtin_bit_cast(unsigned, in.b) : (size_t)slot; // where the outputs go
 
         f32x16 E[2];
         encode_point<NERF_FAST_SINCOS != 0>(px, py, pz, h, E);
@@ -162,9 +164,10 @@ static hipError_t launch_t(const MlpArgs &a, int n_blocks, hipStream_t stream) {
 
 hipError_t nerf_mlp_init() {
     // forward_batch always evaluates the full head, so the sigma-only kernel exists in ray mode only
-    const void *ks[3] = {(const void *)nerf_mlp_kernel<true, MLP_MODE_POINTS>, (const void *)nerf_mlp_kernel<true, MLP_MODE_RAYS>,
-                         (const void *)nerf_mlp_kernel<false, MLP_MODE_RAYS>};
-    for (int i = 0; i < 3; ++i) {
+    const void *ks[5] = {(const void *)nerf_mlp_kernel<true, MLP_MODE_POINTS>, (const void *)nerf_mlp_kernel<true, MLP_MODE_RAYS>,
+                         (const void *)nerf_mlp_kernel<false, MLP_MODE_RAYS>, (const void *)nerf_mlp_kernel<true, MLP_MODE_LIST>,
+                         (const void *)nerf_mlp_kernel<false, MLP_MODE_LIST>};
+    for (int i = 0; i < 5; ++i) {
         hipError_t e = hipFuncSetAttribute(ks[i], hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
         if (e != hipSuccess) return e;
     }
@@ -176,6 +179,10 @@ hipError_t nerf_mlp_launch(const MlpArgs &a, bool full, int n_blocks, hipStream_
     const int n_tiles = (a.n_points + kPointsPerBlock - 1) / kPointsPerBlock;
     if (n_blocks > n_tiles) n_blocks = n_tiles;
     if (n_blocks < 1) n_blocks = 1;
+    if (a.mode == MLP_MODE_LIST) {
+        if (!a.point_list || !a.point_list_count) return hipErrorInvalidValue;
+        return full ? launch_t<true, MLP_MODE_LIST>(a, n_blocks, stream) : launch_t<false, MLP_MODE_LIST>(a, n_blocks, stream);
+    }
     if (a.mode == MLP_MODE_POINTS)
         return full ? launch_t<true, MLP_MODE_POINTS>(a, n_blocks, stream) : hipErrorInvalidValue; // no sigma-only forward_batch
     return full ? launch_t<true, MLP_MODE_RAYS>(a, n_blocks, stream) : launch_t<false, MLP_MODE_RAYS>(a, n_blocks, stream);

@@ -507,8 +507,11 @@ __global__ __launch_bounds__(256, 1) void nerf_mlp_kernel_bf16v2(const MlpArgs A
         for (int c = 0; c < 3; ++c) H.rgb[0][c] = H.rgb[1][c] = 0.f;
 
         trunk_layers<FULL>(E0, E1, X0, X1, Y0, Y1, C, small, H, P, h);
-        const float s0 = fmaxf(xhalf_sum(H.alpha[0]) + small[kMiscOff + 0], 0.f); // ReLU(alpha) (src/network.rs:216)
-        const float s1 = fmaxf(xhalf_sum(H.alpha[1]) + small[kMiscOff + 0], 0.f);
+        const float pre0 = xhalf_sum(H.alpha[0]) + small[kMiscOff + 0], pre1 = xhalf_sum(H.alpha[1]) + small[kMiscOff + 0];
+        // raw_pre (zero certification, nerf_api.cpp): the pre-activation itself leaves the kernel -- how far below 0 it is decides
+        // whether the f32 kernel needs to look at the sample at all
+        const float s0 = A.raw_pre ? pre0 : fmaxf(pre0, 0.f); // ReLU(alpha) (src/network.rs:216)
+        const float s1 = A.raw_pre ? pre1 : fmaxf(pre1, 0.f);
         if (h == 0) {
             if (v0) A.sigma_out[i0] = s0;
             if (v1) A.sigma_out[i1] = s1;

@@ -347,6 +347,9 @@ int nerfint::render_device(nerf_ctx *c, const nerf_camera *cam, const nerf_rende
     const bool seq = o->skip_dead != 0;
     if (seq && dtype == NERF_MLP_BF16 && !g_bf16_v2) return fail(c, NERF_ERR_INVALID, "skip_dead with NERF_MLP_BF16 is not part of the NERF_BF16_V3 variant build");
     if (o->hybrid_sampling != 0 && o->hybrid_sampling != 1) return fail(c, NERF_ERR_INVALID, "hybrid_sampling must be 0 or 1");
+    if (o->certify_zero != 0 && o->certify_zero != 1) return fail(c, NERF_ERR_INVALID, "certify_zero must be 0 or 1");
+    if (o->certify_zero && (dtype != NERF_MLP_F32 || seq || o->skip_empty || !g_bf16_v2))
+        return fail(c, NERF_ERR_INVALID, "certify_zero needs mlp_dtype F32 and neither skip_empty nor skip_dead");
     if (o->hybrid_sampling && !(seq && !o->coarse_only && dtype != NERF_MLP_BF16)) // bf16 is its own arithmetic: there are no f32 sample positions to protect
         return fail(c, NERF_ERR_INVALID, "hybrid_sampling needs skip_dead = 1, mlp_dtype F32, BF16X3 or F16X2, and a hierarchical render");
     if (!c->net[NERF_NET_COARSE].loaded) return fail(c, NERF_ERR_STATE, "coarse network not loaded");
@@ -426,6 +429,21 @@ int nerfint::render_device(nerf_ctx *c, const nerf_camera *cam, const nerf_rende
         }
         if (hybrid && (rc = ensure_bytes(c, (void **)&c->d_flag_list, &c->flag_list_bytes, rows_per_pass * RW * sizeof(unsigned int)))) return rc;
     }
+    // Zero certification (nerf_render_opts.certify_zero; f32 renders without skip modes): a bf16 pass over all samples finds the
+    // ones whose density pre-activation is so far below 0 (coarse: < -1, fine: < -2; NERF_CERTIFY_MARGINS="c,f") that the f32 network's
+    // density is certainly 0 there too -- several times the largest bf16-vs-f32 difference seen on such samples -- and the f32 kernel
+    // evaluates only the rest (a device-side list).  A certified sample has sigma = 0 => weight 0: the frame is the f32 frame, bit for bit,
+    // as long as no certificate is wrong.  DESIGN 9.
+    float cert_margin[2] = {1.0f, 2.0f};
+    bool certify = false;
+    certify = o->certify_zero != 0;
+    if (certify) {
+        if (const char *env = getenv("NERF_CERTIFY_MARGINS")) (void)sscanf(env, "%f,%f", &cert_margin[0], &cert_margin[1]);
+        const size_t n_pass = ((size_t)RH + rows_per_pass - 1) / rows_per_pass;
+        if ((rc = ensure_bytes(c, (void **)&c->d_point_list, &c->point_list_bytes, rows_per_pass * RW * (size_t)M * sizeof(unsigned int)))) return rc;
+        if ((rc = ensure_bytes(c, (void **)&c->d_cert, &c->cert_bytes, 2 * n_pass * sizeof(unsigned int)))) return rc;
+        HIP_TRY(c, hipMemsetAsync(c->d_cert, 0, 2 * n_pass * sizeof(unsigned int), st));
+    }
     recycle_render(c);
     recycle_dominant(c, 4096); // bound the backlog if the caller never queries
     // If this render returns early (a launch failed), its dominant-kernel event pairs never reach c->dominant: hand them back
@@ -488,6 +506,28 @@ int nerfint::render_device(nerf_ctx *c, const nerf_camera *cam, const nerf_rende
         a.mode = MLP_MODE_RAYS;
         a.ray_dirs = c->d_dirs;
         a.origin[0] = cam->pos[0]; a.origin[1] = cam->pos[1]; a.origin[2] = cam->pos[2];
+        // zero certification: bf16 pre-activations of all samples -> list of the samples that are not certain zeros -> f32 kernel on the list
+        auto cert_pass = [&](const DevNet &net, int which, int spr, const float *t_in, float *sigma_out, float *rgb_out, int kind) -> int {
+            const int n_pts = n_rays * spr;
+            unsigned int *cnt = c->d_cert + 2 * (size_t)passes + which;
+            MlpArgs b = a;
+            b.wstream = stream_of(net, NERF_MLP_BF16); b.small_params = net.small; b.n_points = n_pts; b.samples_per_ray = spr; b.t = t_in;
+            b.sigma_out = sigma_out; b.rgb_out = nullptr; b.raw_pre = 1;
+            {
+                Timed t(c, st, which == 0 && !rgb_out ? 0 : 4, 0, timing);
+                HIP_TRY(c, launch_mlp(c, NERF_MLP_BF16, b, false, st));
+                HIP_TRY(c, launch_uncertain_list(sigma_out, n_pts, cert_margin[which], c->d_point_list, cnt, st));
+                if (rgb_out) HIP_TRY(c, hipMemsetAsync(rgb_out, 0, (size_t)n_pts * 3 * sizeof(float), st)); // a certain zero has weight 0: 0 * 0
+                t.done(c->last_render);
+            }
+            MlpArgs l = b;
+            l.wstream = stream_of(net, NERF_MLP_F32); l.raw_pre = 0; l.mode = MLP_MODE_LIST; l.rgb_out = rgb_out;
+            l.point_list = c->d_point_list; l.point_list_count = cnt;
+            Timed t(c, st, kind, (uint64_t)n_pts, timing);
+            HIP_TRY(c, launch_mlp(c, NERF_MLP_F32, l, rgb_out != nullptr, st));
+            t.done(c->last_render);
+            return NERF_OK;
+        };
         // coarse network: sigma only unless its colours are composited (reference discards them, src/lib.rs:404)
         a.wstream = stream_of(NC, dtype_coarse); a.small_params = NC.small;
         a.n_points = n_rays * nc; a.samples_per_ray = nc; a.t = c->d_tc;
@@ -496,6 +536,8 @@ int nerfint::render_device(nerf_ctx *c, const nerf_camera *cam, const nerf_rende
         a.nonfinite = split_dtype(dtype_coarse) ? c->d_nonfinite : nullptr;
         if (seq) {
             if ((rc = seq_pass(NC, dtype_coarse, nc, c->d_tc, c->d_sc, o->coarse_only ? c->d_rgbc : nullptr, 3 * (int)passes, o->coarse_only ? 1 : 0))) return rc;
+        } else if (certify) {
+            if ((rc = cert_pass(NC, 0, nc, c->d_tc, c->d_sc, o->coarse_only ? c->d_rgbc : nullptr, o->coarse_only ? 1 : 0))) return rc;
         } else {
             Timed t(c, st, o->coarse_only ? 1 : 0, (uint64_t)a.n_points, timing);
             HIP_TRY(c, launch_mlp(c, dtype_coarse, a, o->coarse_only != 0, st));
@@ -556,6 +598,8 @@ int nerfint::render_device(nerf_ctx *c, const nerf_camera *cam, const nerf_rende
         c->clock_valid = c->d_clock != nullptr;
         if (seq) {
             if ((rc = seq_pass(NF, dtype, M, t_fine, c->d_sf, c->d_rgbf, 3 * (int)passes + 1, 1))) return rc;
+        } else if (certify) {
+            if ((rc = cert_pass(NF, 1, M, t_fine, c->d_sf, c->d_rgbf, 1))) return rc;
         } else {
             Timed t(c, st, 1, (uint64_t)a.n_points, timing);
             HIP_TRY(c, launch_mlp(c, dtype, a, true, st));
@@ -614,6 +658,15 @@ int nerfint::render_device(nerf_ctx *c, const nerf_camera *cam, const nerf_rende
         stats->n_exec_coarse_trunk = stats->n_coarse_points;
         stats->n_exec_fine_trunk = stats->n_fine_points;
         stats->n_exec_colour = (o->coarse_only ? stats->n_coarse_points : stats->n_fine_points) - stats->n_colour_skipped_points;
+        if (certify) { // samples the f32 kernel evaluated = the lengths of the lists
+            std::vector<unsigned int> h((size_t)passes * 2);
+            HIP_TRY(c, hipMemcpy(h.data(), c->d_cert, h.size() * sizeof(unsigned int), hipMemcpyDeviceToHost));
+            uint64_t n0 = 0, n1 = 0;
+            for (uint32_t k = 0; k < passes; ++k) { n0 += h[2 * (size_t)k]; n1 += h[2 * (size_t)k + 1]; }
+            stats->n_exec_coarse_trunk = n0;
+            stats->n_exec_fine_trunk = o->coarse_only ? 0 : n1;
+            stats->n_exec_colour = o->coarse_only ? n0 : n1;
+        }
         if (seq) {
             std::vector<unsigned int> h((size_t)passes * 3 * 4);
             HIP_TRY(c, hipMemcpy(h.data(), c->d_seq, h.size() * sizeof(unsigned int), hipMemcpyDeviceToHost));
@@ -645,7 +698,7 @@ int nerfint::render_device(nerf_ctx *c, const nerf_camera *cam, const nerf_rende
 
 extern "C" {
 
-int nerf_abi_version(void) { return 3; }
+int nerf_abi_version(void) { return 4; }
 
 void nerf_abi_struct_sizes(size_t *camera, size_t *render_opts, size_t *stats) {
     if (camera) *camera = sizeof(nerf_camera);
@@ -737,6 +790,8 @@ void nerf_destroy(nerf_ctx *c) {
     if (c->d_h8) (void)hipFree(c->d_h8);
     if (c->d_slot_point) (void)hipFree(c->d_slot_point);
     if (c->d_flag_list) (void)hipFree(c->d_flag_list);
+    if (c->d_point_list) (void)hipFree(c->d_point_list);
+    if (c->d_cert) (void)hipFree(c->d_cert);
     recycle_render(c);
     recycle_dominant(c, 0);
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);

@@ -16,7 +16,7 @@
 static void usage(const char *argv0) {
     fprintf(stderr,
             "usage: %s [--scene DIR] [--width W] [--height H] [--coarse N] [--fine N] [--seed S] [--ssaa S]\n"
-            "          [--coarse-only] [--crop X0,Y0,W,H] [--dtype f32|bf16|bf16x3|f16x2] [--skip-empty] [--skip-dead] [--hybrid-sampling]\n"
+            "          [--coarse-only] [--crop X0,Y0,W,H] [--dtype f32|bf16|bf16x3|f16x2] [--skip-empty] [--skip-dead] [--hybrid-sampling] [--certify-zero]\n"
             "          [--device ID | --gpus N | --devices ID,ID,... [--gather host|peer|rccl]] [--frames K] [--out FILE.ppm]\n"
             "defaults: --scene lego_rust --width 256 --height 256 --coarse 64 --fine 128 --out output.ppm\n",
             argv0);
@@ -45,6 +45,7 @@ int main(int argc, char **argv) {
         else if (a == "--skip-empty") opts.skip_empty = 1;
         else if (a == "--skip-dead") opts.skip_dead = 1;
         else if (a == "--hybrid-sampling") opts.hybrid_sampling = 1;
+        else if (a == "--certify-zero") opts.certify_zero = 1;
         else if (a == "--gpus") gpus = atoi(next());
         else if (a == "--devices") { // explicit device list, one context each (ids may repeat: several contexts on one GPU)
             devices.clear();

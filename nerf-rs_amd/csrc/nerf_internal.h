@@ -49,6 +49,8 @@ struct nerf_ctx {
     float *d_h8 = nullptr; size_t h8_bytes = 0;
     unsigned int *d_slot_point = nullptr; size_t slot_point_bytes = 0;
     unsigned int *d_flag_list = nullptr; size_t flag_list_bytes = 0; // hybrid sampling: rays whose coarse pass is redone in f32
+    unsigned int *d_point_list = nullptr; size_t point_list_bytes = 0; // zero certification (experimental): samples the f32 kernel evaluates
+    unsigned int *d_cert = nullptr; size_t cert_bytes = 0;             // ... and their counts: [2 * pass + (0 coarse | 1 fine)]
     float hybrid_tau = 1e-5f;                                        // a draw predicted to move by more than this (in t) flags its ray
     size_t max_export_bytes = (size_t)16 << 30; // budget of d_h8: bounds the rays per pass of skip_dead in a SPLIT arithmetic (NERF_MAX_EXPORT_BYTES);
                                                 // 16 GiB = 8 passes per 800x800 frame, 1.4 % slower than one pass of 128 GiB

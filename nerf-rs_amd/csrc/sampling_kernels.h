@@ -59,3 +59,5 @@ hipError_t launch_composite(const CompositeArgs &a, hipStream_t st);
 hipError_t launch_box_downsample(const float *rays, float *out, int w, int h, int s, hipStream_t st);
 size_t resample_lds_bytes(int nc, int nf);
 size_t composite_lds_bytes(int n);
+// zero certification (experimental, nerf_api.cpp): list the samples whose bf16 pre-activation is not below -margin; zeroes `pre`
+hipError_t launch_uncertain_list(float *pre, int n, float margin, unsigned *list, unsigned *count, hipStream_t st);

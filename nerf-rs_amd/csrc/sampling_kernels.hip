@@ -383,6 +383,30 @@ __global__ void k_box_downsample(const float *__restrict__ rays, float *__restri
     out[idx] = acc * (1.0f / (float)(s * s));
 }
 
+// ---- zero certification (experimental): which samples does the f32 kernel have to look at? ---------------------------------
+// `pre` holds the bf16 kernel's density PRE-activations.  A sample whose pre-activation is below -margin is a certain zero of the f32
+// network too (margin = several times the largest bf16-vs-f32 difference ever seen on such samples); every other sample -- positive,
+// near zero, NaN -- goes on the list.  The buffer is zeroed on the way: it becomes the f32 pass's sigma buffer, whose listed entries
+// the f32 kernel overwrites.  List order is arbitrary (one atomic per wave); results do not depend on it.
+__global__ void k_uncertain_list(float *__restrict__ pre, int n, float margin, unsigned *__restrict__ list, unsigned *__restrict__ count) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    bool unc = false;
+    if (i < n) { unc = !(pre[i] < -margin); pre[i] = 0.0f; }
+    const unsigned long long m = __ballot(unc);
+    if (m == 0) return;
+    const int lane = threadIdx.x & 63;
+    unsigned base = 0;
+    if (lane == 0) base = atomicAdd(count, (unsigned)__popcll(m));
+    base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+    if (unc) list[base + (unsigned)__popcll(m & ((1ull << lane) - 1ull))] = (unsigned)i;
+}
+
+hipError_t launch_uncertain_list(float *pre, int n, float margin, unsigned *list, unsigned *count, hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_uncertain_list, dim3((n + 255) / 256), dim3(256), 0, st, pre, n, margin, list, count);
+    return hipGetLastError();
+}
+
 // ---- launchers -----------------------------------------------------------------------------------------
 hipError_t launch_ray_dirs(const RayGenArgs &a, float *dirs, hipStream_t st) {
     if (a.n_rays <= 0) return hipSuccess;

@@ -15,7 +15,7 @@ def band_of_rank(n_rows, rank, world_size):
 
 
 def render_image_distributed(coarse, fine, camera, fine_samples_per_ray=128, *, seed=0, coarse_only=False, crop=None,
-                             ssaa=1, dtype="f32", skip_empty=False, skip_dead=False, hybrid_sampling=False, group=None,
+                             ssaa=1, dtype="f32", skip_empty=False, skip_dead=False, hybrid_sampling=False, certify_zero=False, group=None,
                              band_renderer=None, device=None, return_tensor=False, timings=None):
     """render_image over all ranks of `group` (torch.distributed; backend nccl == RCCL on ROCm, gloo in CPU tests).
 
@@ -50,7 +50,7 @@ def render_image_distributed(coarse, fine, camera, fine_samples_per_ray=128, *, 
             stream = torch.cuda.current_stream(dev).cuda_stream
             render_image(coarse, fine, camera, fine_samples_per_ray, seed=seed, coarse_only=coarse_only, crop=band_crop,
                          ssaa=ssaa, dtype=dtype, skip_empty=skip_empty, skip_dead=skip_dead, hybrid_sampling=hybrid_sampling,
-                         device_out=band.data_ptr(), stream=stream)
+                         certify_zero=certify_zero, device_out=band.data_ptr(), stream=stream)
     if marks: marks.stamp(band.device)  # band rendered (GPU: an event on the render stream)
     if band.device.type == "cuda" and dist.get_backend(group) != "nccl":
         # rehearsal only (e.g. gloo with several ranks on one GPU): the collective runs on host copies of the bands

@@ -27,7 +27,7 @@ def test_abi_exports_every_declared_symbol(native):
         assert hasattr(L, name), f"{name} declared in the header but not exported"
         assert name in _lib.PROTOTYPES, f"{name} has no ctypes prototype"
     assert set(_lib.PROTOTYPES) == declared
-    assert native.load_library().nerf_abi_version() == 3
+    assert native.load_library().nerf_abi_version() == 4
     assert native.load_library().nerf_build_variant() == b""      # the product build; variants carry a tag and are refused by the loader
 
 
@@ -453,7 +453,7 @@ def test_struct_sizes_match_the_library(native):
     L = native.load_library()
     a, b, c = C.c_size_t(), C.c_size_t(), C.c_size_t()
     L.nerf_abi_struct_sizes(C.byref(a), C.byref(b), C.byref(c))
-    assert (a.value, b.value, c.value) == (C.sizeof(_lib.CCamera), C.sizeof(_lib.COpts), C.sizeof(_lib.CStats)) == (60, 56, 112)
+    assert (a.value, b.value, c.value) == (C.sizeof(_lib.CCamera), C.sizeof(_lib.COpts), C.sizeof(_lib.CStats)) == (60, 64, 112)
 
 
 def test_loader_rejects_a_directory_named_like_a_tensor(native, tmp_path):
@@ -470,10 +470,10 @@ def test_render_opts_mirror_maps_every_field(native):
     from nerf_rs_amd.api import RenderOpts, _DTYPES
     assert (_DTYPES["f32"], _DTYPES["bf16"], _DTYPES["bf16x3"], _DTYPES["f16x2"]) == (0, 1, 2, 3)
     o = RenderOpts(n_coarse=40, n_fine=50, coarse_only=True, crop=(1, 2, 3, 4), ssaa=2, seed=(1 << 40) + 7, dtype="f16x2",
-                   skip_empty=True, skip_dead=True, hybrid_sampling=True).to_c()
+                   skip_empty=True, skip_dead=True, hybrid_sampling=True, certify_zero=True).to_c()
     got = {name: getattr(o, name) for name, _ in type(o)._fields_}
     assert got == {"n_coarse": 40, "n_fine": 50, "coarse_only": 1, "crop_x0": 1, "crop_y0": 2, "crop_w": 3, "crop_h": 4, "ssaa": 2,
-                   "seed": (1 << 40) + 7, "mlp_dtype": 3, "skip_empty": 1, "skip_dead": 1, "hybrid_sampling": 1}
+                   "seed": (1 << 40) + 7, "mlp_dtype": 3, "skip_empty": 1, "skip_dead": 1, "hybrid_sampling": 1, "certify_zero": 1}
     z = RenderOpts().to_c()
     assert (z.n_coarse, z.n_fine, z.mlp_dtype, z.skip_empty, z.skip_dead, z.hybrid_sampling, z.crop_w, z.ssaa) == (64, 128, 0, 0, 0, 0, 0, 1)
 

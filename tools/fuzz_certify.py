@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""Fuzz of zero certification (nerf_render_opts.certify_zero): random poses (any azimuth, +-25 degrees tilt), frame sizes, windows,
+sample counts, seeds, SSAA, coarse-only -- the certified frame must be the plain f32 frame BIT FOR BIT: one wrong certificate (a sample
+the bf16 pass declares a certain zero while the f32 network gives it a density) that reaches a pixel shows up as a mismatch.
+Usage: fuzz_certify.py [seconds] [rng seed]   (exit code 1 on a mismatch; tests/test_gpu_certify.py runs a short one)"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import nerf_rs_amd as N
+from scene_utils import pose
+
+S = json.load(open(os.path.join(ROOT, "lego_rust", "tf_reference_samples.json")))
+
+
+def fuzz(r, budget, rng_seed):
+    rng = np.random.default_rng(rng_seed)
+    tot = dict(cases=0, rays=0, mismatching=0, f32_samples_nominal=0, f32_samples_evaluated=0)
+    t_end = time.time() + budget
+    while time.time() < t_end:
+        W = int(rng.choice([64, 128, 200, 400, 800]))
+        nc, nf = [(64, 128), (64, 128), (48, 96), (32, 64), (20, 50), (33, 77), (64, 0), (7, 5)][int(rng.integers(8))]
+        cam = N.camera_from_pose(pose(S, float(rng.uniform(0, 360)), float(rng.uniform(-25, 25))), S["hwf"], S["near"], S["far"], W, W, nc)
+        w, h = int(rng.integers(1, min(W, 200) + 1)), int(rng.integers(1, min(W, 48) + 1))
+        kw = dict(seed=int(rng.integers(0, 1 << 30)), crop=(int(rng.integers(0, W - w + 1)), int(rng.integers(0, W - h + 1)), w, h),
+                  ssaa=2 if rng.integers(6) == 0 else 1, coarse_only=(nf == 0))
+        ref = N.render_image(r.coarse, r.fine, cam, nf, **kw)
+        img, st = N.render_image(r.coarse, r.fine, cam, nf, certify_zero=True, return_stats=True, **kw)
+        tot["cases"] += 1; tot["rays"] += st.n_rays
+        tot["f32_samples_nominal"] += st.n_coarse_points + st.n_fine_points
+        tot["f32_samples_evaluated"] += st.n_exec_coarse_trunk + st.n_exec_fine_trunk
+        if not np.array_equal(img, ref):
+            tot["mismatching"] += 1
+            d = np.abs(img - ref)
+            print(f"MISMATCH: W {W} {nc}+{nf} {kw}: max {d.max():.3e}, {int((d.max(axis=2) > 0).sum())} pixels", flush=True)
+    return tot
+
+
+if __name__ == "__main__":
+    with N.Renderer(0) as r:
+        r.load_scene(os.path.join(ROOT, "lego_rust"))
+        res = fuzz(r, float(sys.argv[1]) if len(sys.argv) > 1 else 60.0, int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+    print(json.dumps(res))
+    sys.exit(1 if res["mismatching"] else 0)
