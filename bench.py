@@ -162,6 +162,10 @@ def main():
                          "the roofline line is then the ray-sequential trunk kernel priced in EXECUTED flops")
     ap.add_argument("--hybrid-sampling", action="store_true",
                     help="with --skip-dead and --dtype bf16x3|f16x2 (profiling runs): sampling pass in the split arithmetic, ill-conditioned rays redone in f32")
+    ap.add_argument("--certify-zero", action="store_true",
+                    help="reported separately, not the headline: zero certification as the timed path (profiling runs; f32 only): a bf16 pass "
+                         "certifies the samples whose density is certainly 0, the f32 kernel evaluates the rest; the roofline line then prices "
+                         "the f32 list kernel in EXECUTED flops")
     ap.add_argument("--skip-empty", action="store_true",
                     help="SURVEY 8f.2 (reported separately, not the headline): skip the colour head of all-empty tiles; "
                          "the image is bit-identical, the roofline line then prices EXECUTED flops")
@@ -234,11 +238,11 @@ def main():
         if not use_dist or weak:
             N.render_image(r.coarse, r.fine, cam, args.fine, seed=view_seed, ssaa=args.ssaa, dtype=args.dtype,
                            skip_empty=args.skip_empty, skip_dead=args.skip_dead, hybrid_sampling=args.hybrid_sampling,
-                           device_out=frame.data_ptr(), stream=stream)
+                           certify_zero=args.certify_zero, device_out=frame.data_ptr(), stream=stream)
             return frame
         return N.render_image_distributed(r.coarse, r.fine, cam, args.fine, seed=args.seed, ssaa=args.ssaa, dtype=args.dtype,
                                           skip_empty=args.skip_empty, skip_dead=args.skip_dead, hybrid_sampling=args.hybrid_sampling,
-                                          group=data_group, return_tensor=True, timings=marks)
+                                          certify_zero=args.certify_zero, group=data_group, return_tensor=True, timings=marks)
 
     def fence():
         if use_dist:
@@ -282,9 +286,14 @@ def main():
         dead_stats = N.render_image(r.coarse, r.fine, cam, args.fine, seed=args.seed, ssaa=args.ssaa, dtype=args.dtype, skip_dead=True,
                                     hybrid_sampling=args.hybrid_sampling, device_out=frame.data_ptr(), stream=stream, return_stats=True)
         r.kernel_time_query(reset=True)
+    cert_stats = None
+    if args.certify_zero and world == 1:  # one extra untimed frame with stats: the list lengths are deterministic per frame
+        cert_stats = N.render_image(r.coarse, r.fine, cam, args.fine, seed=args.seed, ssaa=args.ssaa, certify_zero=True,
+                                    device_out=frame.data_ptr(), stream=stream, return_stats=True)
+        r.kernel_time_query(reset=True)
     # Reported separately, never part of `value`: the same frame with exact empty-tile skipping.
     extra_skip = None
-    if world == 1 and not args.skip_empty and not args.skip_dead and not args.no_extra:
+    if world == 1 and not args.skip_empty and not args.skip_dead and not args.certify_zero and not args.no_extra:
         def skip_step():
             N.render_image(r.coarse, r.fine, cam, args.fine, seed=args.seed, ssaa=args.ssaa, dtype=args.dtype, skip_empty=True,
                            device_out=frame.data_ptr(), stream=stream)
@@ -303,7 +312,7 @@ def main():
     # Reported separately (the rest of it), never part of `value`: the same frame with exact dead-sample skipping --
     # rays retired at the reference's T < 1e-4 cut, colour head only on samples with weight > 0 -- priced in EXECUTED flops.
     extra_dead = None
-    if world == 1 and args.dtype == "f32" and not args.skip_empty and not args.skip_dead and not args.no_extra:
+    if world == 1 and args.dtype == "f32" and not args.skip_empty and not args.skip_dead and not args.certify_zero and not args.no_extra:
         def dead_step(stats=False):
             return N.render_image(r.coarse, r.fine, cam, args.fine, seed=args.seed, ssaa=args.ssaa, skip_dead=True,
                                   device_out=frame.data_ptr(), stream=stream, return_stats=stats)
@@ -352,8 +361,33 @@ def main():
     # Reported separately, never part of `value`: the same frame in the opt-in f32-accurate operand-splitting arithmetics
     # (three bf16 parts, six products; DESIGN 4.7 f16x2: two f16 parts, three products), each also with
     # exact dead-sample skipping on top.  The coarse (sampling) pass stays on the f32 MFMA kernel in both.
+    # Reported separately, never part of `value`: zero certification -- the same f32 frame, bit for bit, with the f32 kernel
+    # evaluating only the samples a bf16 pass could not certify as zero-density.
+    extra_cert = None
+    if world == 1 and args.dtype == "f32" and not args.skip_empty and not args.skip_dead and not args.certify_zero and not args.no_extra:
+        def cert_step(stats=False):
+            return N.render_image(r.coarse, r.fine, cam, args.fine, seed=args.seed, ssaa=args.ssaa, certify_zero=True,
+                                  device_out=frame.data_ptr(), stream=stream, return_stats=stats)
+        step(); torch.cuda.synchronize(dev)
+        ref_frame = frame.clone()
+        st = cert_step(stats=True); torch.cuda.synchronize(dev)
+        identical = bool(torch.equal(frame, ref_frame))
+        t1 = time.perf_counter()
+        for _ in range(3):
+            cert_step()
+        torch.cuda.synchronize(dev)
+        ms = 1e3 * (time.perf_counter() - t1) / 3
+        n_r = args.width * args.height * args.ssaa * args.ssaa
+        extra_cert = {"rays_per_s": n_r / (ms * 1e-3), "ms_per_step": ms, "image_bit_identical_to_headline_run": identical,
+                      "f32_evaluated_fraction_coarse": st.n_exec_coarse_trunk / max(st.n_coarse_points, 1),
+                      "f32_evaluated_fraction_fine": st.n_exec_fine_trunk / max(st.n_fine_points, 1),
+                      "device_ms": {"total": st.ms_total, "coarse_bf16_pass_plus_f32_list": st.ms_coarse_mlp, "fine_bf16_pass_plus_f32_list": st.ms_fine_mlp, "other": st.ms_other},
+                      "note": "opt-in certify_zero: a bf16 pass over all samples certifies those whose density pre-activation is below -1 (coarse) / -2 (fine) "
+                              "as zeros of the f32 network too; the f32 MFMA kernel evaluates only the others from a device-side list; certified samples "
+                              "have weight 0, so the frame is the headline frame bit for bit (fuzzed: tools/fuzz_certify.py)"}
+        r.kernel_time_query(reset=True)
     extra_split = {}
-    if world == 1 and args.dtype == "f32" and not args.skip_empty and not args.skip_dead and not args.no_extra:
+    if world == 1 and args.dtype == "f32" and not args.skip_empty and not args.skip_dead and not args.certify_zero and not args.no_extra:
         n_r = args.width * args.height * args.ssaa * args.ssaa
         step(); torch.cuda.synchronize(dev)
         f32_frame = frame.clone()
@@ -488,11 +522,13 @@ def main():
             # launch (colour passes on the LDS-compacted live samples); bf16 / split arithmetics: in a second launch, not priced here -- the colour head
             flops_dom = (n_dom / max(dead_stats.n_passes, 1)) * (dead_stats.n_exec_fine_trunk * N.FLOP_PER_POINT_SIGMA +
                                                                   (0 if two_launch else dead_stats.n_exec_colour * (N.FLOP_PER_POINT_FULL - N.FLOP_PER_POINT_SIGMA)))
+        if cert_stats is not None:  # dominant launch = the f32 list kernel of the fine network: full evaluations of the listed samples
+            flops_dom = n_dom * cert_stats.n_exec_fine_trunk * N.FLOP_PER_POINT_FULL
         ach = mfma_per_flop * flops_dom / (ms_dom * 1e-3) / 1e12 if ms_dom > 0 else 0.0
         traffic, traffic_src, traffic_why = pmc_traffic_bytes(
             (f"void nerf_trunk_seq_kernel_{sfx}<true" if two_launch else "void nerf_trunk_seq_kernel<true") if args.skip_dead else
             "void nerf_mlp_kernel_bf16v2<true" if bf16 else "void nerf_mlp_kernel_bf16x3<true" if x3 else
-            "void nerf_mlp_kernel_f16x2<true" if x2 else "void nerf_mlp_kernel<true")
+            "void nerf_mlp_kernel_f16x2<true" if x2 else "void nerf_mlp_kernel<true, 2" if args.certify_zero else "void nerf_mlp_kernel<true")
         line = {  # noqa: E501
             "metric": "rays/sec, lego 800x800 (64 coarse + 128 fine samples per ray)", "value": value, "unit": "rays/s",
             "n_gpus": world, "ranks": dist.get_world_size() if use_dist else 1,
@@ -517,6 +553,7 @@ def main():
                        "d2h_ms_per_frame": d2h_ms,
                        "rays_per_s_including_d2h": (n_rays / (dt / args.steps + 1e-3 * d2h_ms)) if d2h_ms is not None else None,
                        "skip_empty": bool(args.skip_empty), "skip_dead": bool(args.skip_dead), "hybrid_sampling": bool(args.hybrid_sampling),
+                       "certify_zero": bool(args.certify_zero),
                        "colour_head_skipped_samples_per_frame": skipped_per_launch,
                        "whole_job_fraction_of_mfma_roofline": mfma_per_flop * value * flop_ray / (world * peak * 1e12)},  # per-GPU average
             "roofline": {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
@@ -527,10 +564,12 @@ def main():
                          "kernel": ((f"nerf_trunk_seq_kernel_{sfx}<EXPORT=true> (fine network, ray-sequential trunk; executed flops)" if two_launch else
                                      "nerf_trunk_seq_kernel<EXPORT=true> (fine network, ray-sequential trunk + in-kernel colour passes; executed flops)")
                                     if dead_stats is not None else
+                                    "nerf_mlp_kernel<FULL=true, MODE_LIST> (fine network, the samples a bf16 pass could not certify as zeros; executed flops)"
+                                    if cert_stats is not None else
                                     ("nerf_mlp_kernel_bf16v2" if bf16 else "nerf_mlp_kernel_bf16x3" if x3 else "nerf_mlp_kernel_f16x2" if x2 else "nerf_mlp_kernel") +
                                     "<FULL=true, MODE_RAYS> (fine network)"),
                          "launches": n_dom, "avg_launch_ms": ms_dom / max(n_dom, 1),
-                         "points_per_launch": pts_dom // max(n_dom, 1),
+                         "points_per_launch": (cert_stats.n_exec_fine_trunk if cert_stats is not None else pts_dom // max(n_dom, 1)),
                          "flop_per_point": N.FLOP_PER_POINT_SIGMA if dead_stats is not None else N.FLOP_PER_POINT_FULL,
                          "flop_per_live_point_colour_head": (N.FLOP_PER_POINT_FULL - N.FLOP_PER_POINT_SIGMA) if dead_stats is not None and not two_launch else None},
         }
@@ -546,6 +585,8 @@ def main():
             line["extra_skip_empty"] = extra_skip
         if extra_dead:
             line["extra_skip_dead"] = extra_dead
+        if extra_cert:
+            line["extra_certify_zero"] = extra_cert
         if extra_c5:
             line["extra_c5_bf16_ssaa2"] = extra_c5
         if world == 1 and not args.no_cpu_baseline and not bf16 and not split:
