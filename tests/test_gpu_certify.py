@@ -66,3 +66,16 @@ def test_certify_fuzz_short(renderer):
     res = fuzz_certify.fuzz(renderer, 6.0, 20261004)
     print("\n", res)
     assert res["cases"] > 100 and res["mismatching"] == 0 and res["f32_samples_evaluated"] < 0.6 * res["f32_samples_nominal"], res
+
+
+def test_many_passes(native, samples, monkeypatch):
+    """Small passes (NERF_MAX_RAYS_PER_PASS is read when a context is created): the list and its device-side length are per pass."""
+    monkeypatch.setenv("NERF_MAX_RAYS_PER_PASS", "3000")
+    with native.Renderer(0) as r:
+        r.load_scene(SCENE)
+        cam = native.camera_from_samples(samples, 800, 800, 64)
+        crop = (300, 350, 200, 100)
+        ref = native.render_image(r.coarse, r.fine, cam, 128, seed=4, crop=crop)
+        img, st = native.render_image(r.coarse, r.fine, cam, 128, seed=4, crop=crop, certify_zero=True, return_stats=True)
+        assert st.n_passes >= 7 and np.array_equal(img, ref)
+        assert 0 < st.n_exec_fine_trunk < 0.9 * st.n_fine_points
