@@ -427,6 +427,23 @@ def main():
                 "executed_fraction_fine_trunk": st.n_exec_fine_trunk / max(st.n_fine_points, 1),
                 "executed_fraction_colour_head": st.n_exec_colour / max(st.n_fine_points, 1),
                 "device_ms": {"total": st.ms_total, "coarse_trunk_f32": st.ms_coarse_mlp, f"fine_trunk_plus_colour_{arith}": st.ms_fine_mlp, "other": st.ms_other}}
+            # ... and with zero certification: exact-f32 sampling pass and the split fine pass, each on its certified list
+            def cz_step(stats=False):
+                return N.render_image(r.coarse, r.fine, cam, args.fine, seed=args.seed, ssaa=args.ssaa, dtype=arith, certify_zero=True,
+                                      device_out=frame.data_ptr(), stream=stream, return_stats=stats)
+            cz_step(); cz_step(); torch.cuda.synchronize(dev)
+            t1 = time.perf_counter()
+            for _ in range(3):
+                cz_step()
+            torch.cuda.synchronize(dev)
+            ms = 1e3 * (time.perf_counter() - t1) / 3
+            identical = bool(torch.equal(frame, split_frame))
+            st = cz_step(stats=True)
+            e["with_certify_zero"] = {
+                "rays_per_s": n_r / (ms * 1e-3), "ms_per_step": ms, f"image_bit_identical_to_the_{arith}_frame": identical,
+                "evaluated_fraction_coarse_f32": st.n_exec_coarse_trunk / max(st.n_coarse_points, 1),
+                f"evaluated_fraction_fine_{arith}": st.n_exec_fine_trunk / max(st.n_fine_points, 1),
+                "device_ms": {"total": st.ms_total, "coarse_bf16_pass_plus_f32_list": st.ms_coarse_mlp, f"fine_bf16_pass_plus_{arith}_list": st.ms_fine_mlp, "other": st.ms_other}}
             # ... and with the sampling pass in the split arithmetic too, ill-conditioned rays redone in f32
             def hyb_step(stats=False):
                 return N.render_image(r.coarse, r.fine, cam, args.fine, seed=args.seed, ssaa=args.ssaa, dtype=arith, skip_dead=True,

@@ -100,11 +100,11 @@ typedef struct {
                            * found 0.9 unflagged rays per million beyond it, the largest at 2.8e-5.  Not bit-identical to
                            * hybrid_sampling = 0 (pixels differ by 2e-8 on average); held to the same Gate 1.
                            * nerf_stats.n_hybrid_rays = rays redone in f32. */
-    int32_t certify_zero;  /* ext (ABI 4; mlp_dtype F32, no skip mode): 1 = a bf16 pass over all samples finds those whose density
+    int32_t certify_zero;  /* ext (ABI 4; mlp_dtype F32, BF16X3 or F16X2, no skip mode): 1 = a bf16 pass over all samples finds those whose density
                            * pre-activation is so far below 0 (coarse network: < -1, fine: < -2 -- several times the largest bf16-vs-f32
                            * difference seen on such samples) that the f32 network's density is certainly 0 there as well; the f32
-                           * kernel then evaluates only the other samples (a device-side list: 40 % of the coarse, 21 % of the fine
-                           * samples of the lego frame).  A certified sample has sigma = 0, weight 0: the image is BIT-IDENTICAL to
+                           * kernel -- for the fine pass of a split arithmetic that arithmetic's kernel -- then evaluates only the other
+                           * samples (a device-side list: 40 % of the coarse, 21 % of the fine samples of the lego frame).  A certified sample has sigma = 0, weight 0: the image is BIT-IDENTICAL to
                            * certify_zero = 0 as long as no certificate is wrong (fuzzed: tools/fuzz_certify.py; the margins rest on
                            * measurements, not on a proof -- hence opt-in).  nerf_stats.n_exec_* = samples the f32 kernel evaluated. */
 } nerf_render_opts;

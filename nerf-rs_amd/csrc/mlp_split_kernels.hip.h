@@ -127,16 +127,18 @@ __global__ __launch_bounds__(256, 1) void SPLIT_KERNEL_FUSED(const MlpArgs A) {
     uint64_t clk0 = 0, rt0 = 0;
     if (A.clock_out) { clk0 = __builtin_amdgcn_s_memtime(); rt0 = __builtin_amdgcn_s_memrealtime(); }
 
-    const int n_tiles = (A.n_points + kPointsPerBlock - 1) / kPointsPerBlock;
+    const int n_points = MODE == MLP_MODE_LIST ? (int)*A.point_list_count : A.n_points; // list mode (certify_zero): the length lives on the device
+    const int n_tiles = (n_points + kPointsPerBlock - 1) / kPointsPerBlock;
     RawIn nxt = load_raw<MODE>(A, blockIdx.x, wave, p);
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        const int i = tile * kPointsPerBlock + wave * kPointsPerWave + p;
-        const bool valid = i < A.n_points;
+        const int slot = tile * kPointsPerBlock + wave * kPointsPerWave + p;
+        const bool valid = slot < n_points;
         const RawIn in = nxt;
         nxt = load_raw<MODE>(A, tile + gridDim.x, wave, p);
         float px, py, pz;
         point_of<MODE>(A, in, px, py, pz);
         const float dx = in.dx, dy = in.dy, dz = in.dz;
+        const size_t i = MODE == MLP_MODE_LIST ? (size_t)__builtin_bit_cast(unsigned, in.b) : (size_t)slot; // where the outputs go
 
         f32x16 E[2];
         encode_point<true>(px, py, pz, h, E);
@@ -344,9 +346,9 @@ static hipError_t launch_t(const MlpArgs &a, int n_blocks, hipStream_t stream) {
 
 hipError_t SPLIT_FN_INIT() {
     // forward_batch always evaluates the full head, so the sigma-only kernel exists in ray mode only
-    const void *ks[3] = {(const void *)SPLIT_KERNEL_FUSED<true, MLP_MODE_POINTS>, (const void *)SPLIT_KERNEL_FUSED<true, MLP_MODE_RAYS>,
-                         (const void *)SPLIT_KERNEL_FUSED<false, MLP_MODE_RAYS>};
-    for (int i = 0; i < 3; ++i) {
+    const void *ks[4] = {(const void *)SPLIT_KERNEL_FUSED<true, MLP_MODE_POINTS>, (const void *)SPLIT_KERNEL_FUSED<true, MLP_MODE_RAYS>,
+                         (const void *)SPLIT_KERNEL_FUSED<false, MLP_MODE_RAYS>, (const void *)SPLIT_KERNEL_FUSED<true, MLP_MODE_LIST>};
+    for (int i = 0; i < 4; ++i) {
         hipError_t e = hipFuncSetAttribute(ks[i], hipFuncAttributeMaxDynamicSharedMemorySize, kSplitLdsBytes);
         if (e != hipSuccess) return e;
     }
@@ -358,6 +360,8 @@ hipError_t SPLIT_FN_LAUNCH(const MlpArgs &a, bool full, int n_blocks, hipStream_
     const int n_tiles = (a.n_points + kPointsPerBlock - 1) / kPointsPerBlock;
     if (n_blocks > n_tiles) n_blocks = n_tiles;
     if (n_blocks < 1) n_blocks = 1;
+    if (a.mode == MLP_MODE_LIST) // certify_zero: the fine pass on the listed samples (the coarse pass of a split render is the f32 kernel's)
+        return full && a.point_list && a.point_list_count ? launch_t<true, MLP_MODE_LIST>(a, n_blocks, stream) : hipErrorInvalidValue;
     if (a.mode == MLP_MODE_POINTS)
         return full ? launch_t<true, MLP_MODE_POINTS>(a, n_blocks, stream) : hipErrorInvalidValue; // no sigma-only forward_batch
     return full ? launch_t<true, MLP_MODE_RAYS>(a, n_blocks, stream) : launch_t<false, MLP_MODE_RAYS>(a, n_blocks, stream);

@@ -348,8 +348,8 @@ int nerfint::render_device(nerf_ctx *c, const nerf_camera *cam, const nerf_rende
     if (seq && dtype == NERF_MLP_BF16 && !g_bf16_v2) return fail(c, NERF_ERR_INVALID, "skip_dead with NERF_MLP_BF16 is not part of the NERF_BF16_V3 variant build");
     if (o->hybrid_sampling != 0 && o->hybrid_sampling != 1) return fail(c, NERF_ERR_INVALID, "hybrid_sampling must be 0 or 1");
     if (o->certify_zero != 0 && o->certify_zero != 1) return fail(c, NERF_ERR_INVALID, "certify_zero must be 0 or 1");
-    if (o->certify_zero && (dtype != NERF_MLP_F32 || seq || o->skip_empty || !g_bf16_v2))
-        return fail(c, NERF_ERR_INVALID, "certify_zero needs mlp_dtype F32 and neither skip_empty nor skip_dead");
+    if (o->certify_zero && (dtype == NERF_MLP_BF16 || seq || o->skip_empty || !g_bf16_v2))
+        return fail(c, NERF_ERR_INVALID, "certify_zero needs mlp_dtype F32, BF16X3 or F16X2 and neither skip_empty nor skip_dead");
     if (o->hybrid_sampling && !(seq && !o->coarse_only && dtype != NERF_MLP_BF16)) // bf16 is its own arithmetic: there are no f32 sample positions to protect
         return fail(c, NERF_ERR_INVALID, "hybrid_sampling needs skip_dead = 1, mlp_dtype F32, BF16X3 or F16X2, and a hierarchical render");
     if (!c->net[NERF_NET_COARSE].loaded) return fail(c, NERF_ERR_STATE, "coarse network not loaded");
@@ -507,7 +507,7 @@ int nerfint::render_device(nerf_ctx *c, const nerf_camera *cam, const nerf_rende
         a.ray_dirs = c->d_dirs;
         a.origin[0] = cam->pos[0]; a.origin[1] = cam->pos[1]; a.origin[2] = cam->pos[2];
         // zero certification: bf16 pre-activations of all samples -> list of the samples that are not certain zeros -> f32 kernel on the list
-        auto cert_pass = [&](const DevNet &net, int which, int spr, const float *t_in, float *sigma_out, float *rgb_out, int kind) -> int {
+        auto cert_pass = [&](const DevNet &net, int which, int dt, int spr, const float *t_in, float *sigma_out, float *rgb_out, int kind) -> int {
             const int n_pts = n_rays * spr;
             unsigned int *cnt = c->d_cert + 2 * (size_t)passes + which;
             MlpArgs b = a;
@@ -521,10 +521,11 @@ int nerfint::render_device(nerf_ctx *c, const nerf_camera *cam, const nerf_rende
                 t.done(c->last_render);
             }
             MlpArgs l = b;
-            l.wstream = stream_of(net, NERF_MLP_F32); l.raw_pre = 0; l.mode = MLP_MODE_LIST; l.rgb_out = rgb_out;
+            l.wstream = stream_of(net, dt); l.raw_pre = 0; l.mode = MLP_MODE_LIST; l.rgb_out = rgb_out;
             l.point_list = c->d_point_list; l.point_list_count = cnt;
+            l.nonfinite = split_dtype(dt) ? c->d_nonfinite : nullptr;
             Timed t(c, st, kind, (uint64_t)n_pts, timing);
-            HIP_TRY(c, launch_mlp(c, NERF_MLP_F32, l, rgb_out != nullptr, st));
+            HIP_TRY(c, launch_mlp(c, dt, l, rgb_out != nullptr, st));
             t.done(c->last_render);
             return NERF_OK;
         };
@@ -537,7 +538,7 @@ int nerfint::render_device(nerf_ctx *c, const nerf_camera *cam, const nerf_rende
         if (seq) {
             if ((rc = seq_pass(NC, dtype_coarse, nc, c->d_tc, c->d_sc, o->coarse_only ? c->d_rgbc : nullptr, 3 * (int)passes, o->coarse_only ? 1 : 0))) return rc;
         } else if (certify) {
-            if ((rc = cert_pass(NC, 0, nc, c->d_tc, c->d_sc, o->coarse_only ? c->d_rgbc : nullptr, o->coarse_only ? 1 : 0))) return rc;
+            if ((rc = cert_pass(NC, 0, dtype_coarse, nc, c->d_tc, c->d_sc, o->coarse_only ? c->d_rgbc : nullptr, o->coarse_only ? 1 : 0))) return rc;
         } else {
             Timed t(c, st, o->coarse_only ? 1 : 0, (uint64_t)a.n_points, timing);
             HIP_TRY(c, launch_mlp(c, dtype_coarse, a, o->coarse_only != 0, st));
@@ -599,7 +600,7 @@ int nerfint::render_device(nerf_ctx *c, const nerf_camera *cam, const nerf_rende
         if (seq) {
             if ((rc = seq_pass(NF, dtype, M, t_fine, c->d_sf, c->d_rgbf, 3 * (int)passes + 1, 1))) return rc;
         } else if (certify) {
-            if ((rc = cert_pass(NF, 1, M, t_fine, c->d_sf, c->d_rgbf, 1))) return rc;
+            if ((rc = cert_pass(NF, 1, dtype, M, t_fine, c->d_sf, c->d_rgbf, 1))) return rc;
         } else {
             Timed t(c, st, 1, (uint64_t)a.n_points, timing);
             HIP_TRY(c, launch_mlp(c, dtype, a, true, st));

@@ -1,5 +1,6 @@
 """certify_zero (nerf_render_opts.certify_zero, ABI 4): a bf16 pass over all samples certifies those whose density pre-activation is
-far below 0; the f32 kernel (nerf_mlp_kernel<.., MLP_MODE_LIST>) evaluates only the others.  A certified sample has sigma = 0 in the
+far below 0; the f32 kernel (nerf_mlp_kernel<.., MLP_MODE_LIST>; for the fine pass of a split arithmetic that arithmetic's kernel)
+evaluates only the others.  A certified sample has sigma = 0 in the
 f32 network too, hence weight 0 (src/lib.rs:271-272): the frame must be the plain f32 frame BIT FOR BIT -- which the whole-frame
 fixture tests hold to Gate 1 against the oracle (tests/test_gpu_frame_fixture.py)."""
 import os
@@ -54,9 +55,25 @@ def test_through_bands_and_option_checks(renderer, native, samples):
     finally:
         for r in rs:
             r.close()
-    for bad in (dict(skip_dead=True), dict(skip_empty=True), dict(dtype="f16x2"), dict(dtype="bf16")):
+    for bad in (dict(skip_dead=True), dict(skip_empty=True), dict(dtype="bf16")):
         with pytest.raises(native.NerfError, match="certify_zero needs"):
             native.render_image(renderer.coarse, renderer.fine, cam, 128, crop=(0, 0, 8, 8), certify_zero=True, **bad)
+
+
+@pytest.mark.parametrize("dtype", ["f16x2", "bf16x3"])
+def test_split_arithmetics_whole_frame(renderer, native, samples, dtype):
+    """The split arithmetics keep their exact-f32 sampling pass (certified as well) and run the fine pass on the certified list: the
+    frame is the plain frame of that arithmetic bit for bit -- which test_gpu_frame_fixture.py holds to the unrelaxed Gate 1 against
+    the oracle's whole frame -- and no operand leaves the arithmetic's range."""
+    cam = native.camera_from_samples(samples, 800, 800, 64)
+    ref, s0 = native.render_image(renderer.coarse, renderer.fine, cam, 128, seed=0, dtype=dtype, return_stats=True)
+    img, st = native.render_image(renderer.coarse, renderer.fine, cam, 128, seed=0, dtype=dtype, certify_zero=True, return_stats=True)
+    print(f"\n{dtype} + certify_zero: {s0.ms_total:.1f} -> {st.ms_total:.1f} ms")
+    assert np.array_equal(img, ref) and st.n_nonfinite_points == 0
+    assert st.ms_total < 0.65 * s0.ms_total
+    co = native.render_image(renderer.coarse, renderer.fine, cam, 0, seed=0, dtype=dtype, coarse_only=True, crop=(300, 300, 200, 50))
+    assert np.array_equal(native.render_image(renderer.coarse, renderer.fine, cam, 0, seed=0, dtype=dtype, coarse_only=True, crop=(300, 300, 200, 50),
+                                              certify_zero=True), co)
 
 
 def test_certify_fuzz_short(renderer):

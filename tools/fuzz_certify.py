@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Fuzz of zero certification (nerf_render_opts.certify_zero): random poses (any azimuth, +-25 degrees tilt), frame sizes, windows,
-sample counts, seeds, SSAA, coarse-only -- the certified frame must be the plain f32 frame BIT FOR BIT: one wrong certificate (a sample
+sample counts, seeds, SSAA, coarse-only -- in f32 and in the two split arithmetics; the certified frame must be the plain frame of the same arithmetic BIT FOR BIT: one wrong certificate (a sample
 the bf16 pass declares a certain zero while the f32 network gives it a density) that reaches a pixel shows up as a mismatch.
 Usage: fuzz_certify.py [seconds] [rng seed]   (exit code 1 on a mismatch; tests/test_gpu_certify.py runs a short one)"""
 import json
@@ -30,6 +30,7 @@ def fuzz(r, budget, rng_seed):
         w, h = int(rng.integers(1, min(W, 200) + 1)), int(rng.integers(1, min(W, 48) + 1))
         kw = dict(seed=int(rng.integers(0, 1 << 30)), crop=(int(rng.integers(0, W - w + 1)), int(rng.integers(0, W - h + 1)), w, h),
                   ssaa=2 if rng.integers(6) == 0 else 1, coarse_only=(nf == 0))
+        kw["dtype"] = str(rng.choice(["f32", "f32", "f16x2", "bf16x3"]))  # split arithmetics: f32 certified coarse pass + certified fine pass
         ref = N.render_image(r.coarse, r.fine, cam, nf, **kw)
         img, st = N.render_image(r.coarse, r.fine, cam, nf, certify_zero=True, return_stats=True, **kw)
         tot["cases"] += 1; tot["rays"] += st.n_rays

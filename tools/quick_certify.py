@@ -27,5 +27,15 @@ with N.Renderer(0) as r:
         print(f"{W}x{W} crop {crop} {nc}+{nf} coarse_only {co} ssaa {ssaa}: identical={same} (max diff {np.abs(a - b).max():.2e}); plain {best0.ms_total:.1f} ms -> certified {best.ms_total:.1f} ms "
               f"(coarse {best.ms_coarse_mlp:.1f} fine {best.ms_fine_mlp:.1f} other {best.ms_other:.1f}); f32 kernel evaluates coarse {best.n_exec_coarse_trunk / max(best.n_coarse_points, 1):.3f} "
               f"fine {best.n_exec_fine_trunk / max(best.n_fine_points, 1):.3f} of the samples", flush=True)
+    cam = N.camera_from_samples(S, 800, 800, 64)
+    for dt in ("f16x2", "bf16x3"):
+        a = N.render_image(r.coarse, r.fine, cam, 128, seed=1, dtype=dt)
+        best = None
+        for k in range(n):
+            b, st = N.render_image(r.coarse, r.fine, cam, 128, seed=1, dtype=dt, certify_zero=True, return_stats=True)
+            if best is None or st.ms_total < best.ms_total: best = st
+        same = np.array_equal(a, b); ok &= same
+        print(f"{dt} C3 frame: identical={same}; certified {best.ms_total:.1f} ms (coarse {best.ms_coarse_mlp:.1f} fine {best.ms_fine_mlp:.1f} other {best.ms_other:.1f}); "
+              f"nonfinite {best.n_nonfinite_points}", flush=True)
 print("ALL IDENTICAL" if ok else "MISMATCH")
 sys.exit(0 if ok else 1)
