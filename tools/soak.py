@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Determinism soak: the same 800x800 frame N times per arithmetic and mode; every repetition must be bit-identical to the first --
 a race in one of the LDS weight pipelines, in the device-side ray queue / live-sample export of skip_dead, or in the flagged-ray
-list of hybrid_sampling (all filled in arbitrary order) would show up as a sporadic mismatch."""
+list of hybrid_sampling, or in the sample list of certify_zero (all filled in arbitrary order) would show up as a sporadic mismatch."""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -15,6 +15,7 @@ with N.Renderer(0) as r:
     modes = [(d, dict(skip_empty=sk)) for d in ("f32", "bf16x3", "f16x2", "bf16") for sk in (False, True)]
     modes += [(d, dict(skip_dead=True)) for d in ("f32", "bf16x3", "f16x2", "bf16")]
     modes += [(d, dict(skip_dead=True, hybrid_sampling=True)) for d in ("f32", "bf16x3", "f16x2")]
+    modes += [(d, dict(certify_zero=True)) for d in ("f32", "bf16x3", "f16x2")]  # the sample list is filled in arbitrary order
     for dtype, kw in modes:
         t0 = time.time()
         ref = N.render_image(r.coarse, r.fine, cam, 128, seed=0, dtype=dtype, **kw)
