@@ -1,6 +1,6 @@
 """hybrid_sampling beyond the one view its error model was fitted on.  The flag of k_resample (sampling_kernels.hip:
 a first-order bound of |d cdf_j| per bin edge from a density-error bound min(2e-5 + 6e-6 sigma, 2e-4) per sample, plus 6 ulp of
-rounding noise, tau = 1e-5) was fitted on dumped lego views (tools/dump_hybrid_cases.py, tools/fit_hybrid_model.py).
+rounding noise, tau = 1e-5) was fitted on dumped lego views (round-3 tools, removed in round 4; the emulation lives on in tests/helpers/hybrid_model.py).
 Here: rotated poses, other sample counts, a random-weight scene -- each held to the f32 path's own Gate 1 against
 the LIVE oracle -- and the documented promise itself (include/nerf_mi355x.h: "the others move by <= 1e-5 in t"), asserted on the
 sample positions: unflagged rays of the split-arithmetic densities must draw within 1e-5 of the f32 densities' draws.

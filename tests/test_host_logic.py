@@ -493,3 +493,19 @@ def test_loader_refuses_a_variant_build(native, tmp_path):
     env.pop("NERF_ALLOW_VARIANT", None)
     p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env)
     assert p.returncode != 0 and "tuning variant (probe: -DNERF_DIAG_NO_DMA=1)" in p.stderr
+
+
+def test_make_variant_tags_every_compile_line():
+    """The Makefile's own variant recipe (not a hand-made stand-in): with DEFS on the command line -- the documented invocation -- every
+    compile line must carry -DNERF_BUILD_VARIANT, or nerf_build_variant() returns "" and the loader takes a timing-only build for the
+    product (round 3: a target-specific `DEFS +=` was ignored for command-line variables)."""
+    import subprocess
+    csrc = os.path.join(ROOT, "nerf-rs_amd", "csrc")
+    out = subprocess.run(["make", "-n", "-C", csrc, "variant", "NAME=x", "DEFS=-DA=1"], capture_output=True, text=True, check=True).stdout
+    compiles = [l for l in out.splitlines() if " -c " in l]
+    assert len(compiles) >= 11
+    for l in compiles:
+        assert "-DA=1" in l and "-DNERF_BUILD_VARIANT='\"x: -DA=1\"'" in l, l
+    bare = subprocess.run(["make", "-n", "-C", csrc, "variant", "NAME=y"], capture_output=True, text=True, check=True).stdout
+    assert all("-DNERF_BUILD_VARIANT='\"y: \"'" in l for l in bare.splitlines() if " -c " in l)
+    assert subprocess.run(["make", "-C", csrc, "variant"], capture_output=True, text=True).returncode != 0  # NAME is required

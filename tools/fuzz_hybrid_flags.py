@@ -102,7 +102,7 @@ def acceptable(res):
 
 if __name__ == "__main__":
     scene = os.environ.get("NERF_FUZZ_SCENE", os.path.join(ROOT, "lego_rust"))  # another network in the reference's directory format
-    missed = []  # the missed rays themselves, for offline analysis (tools/fit_hybrid_model.py)
+    missed = []  # the missed rays themselves, for offline analysis
     with N.Renderer(0) as r:
         r.load_scene(scene)
         res = fuzz(r, float(sys.argv[1]) if len(sys.argv) > 1 else 60.0, int(sys.argv[2]) if len(sys.argv) > 2 else 1, missed)

@@ -30,19 +30,20 @@ with open(os.path.join(dst, f"{tag}_pmc_summary.csv"), "w") as out:
         out.write(f"\"{k}\",{calls[k]},{dur[k]:.3f}," + ",".join(f"{v.get(n, 0):.6g}" for n in names) + "\n")
 lines = [f"# rocprofv3 summary {tag}", "", "Command: `rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extra" + (" " + extra if extra else "") + "` and",
          "separate `--pmc` passes (`bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extra" + (" " + extra if extra else "") + "`), MI355X, 800x800, 64+128 samples.", "", "## kernel-trace stats", "", "```"]
-lines += open(os.path.join(dst, f"{tag}_kernel_stats.csv")).read().strip().split("\n") + ["```", "", "## derived (PMC pass, one frame)", ""]
+lines += open(os.path.join(dst, f"{tag}_kernel_stats.csv")).read().strip().split("\n") + ["```", "", "## derived (PMC passes; all figures PER DISPATCH = totals of the pass / dispatches -- a pass may hold more than one frame)", ""]
 for k, v in agg.items():
     if not any(n in k for n in ("nerf_mlp_kernel", "nerf_trunk_seq_kernel", "nerf_colour_kernel")) or not v.get("SQ_VALU_MFMA_BUSY_CYCLES"):
         continue
     t = dur[k] * 1e-3
+    nd = max(calls[k], 1)
     clk = v["GRBM_GUI_ACTIVE"] / 8 / t / 1e9
     busy = v["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024 / (v["GRBM_GUI_ACTIVE"] / 8)
     wave = v["SQ_WAVE_CYCLES"]
-    lines.append(f"* `{k}`: {dur[k]:.1f} ms under PMC; effective clock {clk:.2f} GHz (GRBM_GUI_ACTIVE/8/t); MFMA pipe busy "
+    lines.append(f"* `{k}`: {nd} dispatches, {dur[k] / nd:.1f} ms each under PMC; effective clock {clk:.2f} GHz (GRBM_GUI_ACTIVE/8/t); MFMA pipe busy "
                  f"{100 * busy:.1f} % of cycles (SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs; one f32 32x32x2 MFMA = 64 busy cycles, one bf16 32x32x16 = 32); of the wave cycles "
                  f"{100 * v['SQ_WAIT_ANY'] / wave:.1f} % waitcnt/barrier (SQ_WAIT_ANY), {100 * v['SQ_WAIT_INST_ANY'] / wave:.1f} % issue stall "
                  f"(SQ_WAIT_INST_ANY, i.e. waiting for the matrix pipe), {100 * v['SQ_ACTIVE_INST_ANY'] / wave:.1f} % issuing; "
-                 f"HBM traffic FETCH_SIZE x2 (gfx950 correction) = {2 * v.get('FETCH_SIZE', 0) / 1024:.1f} MB, WRITE_SIZE = {v.get('WRITE_SIZE', 0) / 1024:.1f} MB "
+                 f"HBM traffic per dispatch: FETCH_SIZE x2 (gfx950 correction) = {2 * v.get('FETCH_SIZE', 0) / 1024 / nd:.1f} MB, WRITE_SIZE = {v.get('WRITE_SIZE', 0) / 1024 / nd:.1f} MB "
                  f"(algorithmic: weights 2.3 MB + inputs/outputs; the kernel is MFMA-bound, HBM is idle)")
 open(os.path.join(dst, f"{tag}_summary.md"), "w").write("\n".join(lines) + "\n")
 print("\n".join(lines[-4:]))
