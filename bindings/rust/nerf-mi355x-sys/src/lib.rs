@@ -1,4 +1,4 @@
-//! Raw bindings to libnerf_mi355x.so.  One-to-one with include/nerf_mi355x.h (ABI version 3): every function the header
+//! Raw bindings to libnerf_mi355x.so.  One-to-one with include/nerf_mi355x.h (ABI version 5): every function the header
 //! declares is declared here with the same number of arguments (tests/test_host_logic.py parses both and compares);
 //! layouts are `#[repr(C)]` mirrors of `nerf_camera`, `nerf_render_opts`, `nerf_stats` -- call `check_layouts()` once at
 //! start-up to compare their sizes with the library's (`nerf_abi_struct_sizes`).
@@ -68,6 +68,13 @@ pub struct nerf_stats {
     pub n_exec_colour: u64,
     pub n_hybrid_rays: u64,
     pub n_nonfinite_points: u64,
+    pub n_certify_audited: u64,
+    pub n_certify_violations: u64,
+    pub n_certify_retries: u32,
+    pub n_certify_fallback_rays: u32,
+    pub certify_margin: [f32; 2],
+    pub certify_headroom: [f32; 2],
+    pub certify_max_error: [f32; 2],
 }
 
 /// `gather` of `nerf_render_image_multi`
@@ -150,9 +157,9 @@ pub fn check_layouts() -> Result<(), String> {
     let (mut a, mut b, mut c) = (0usize, 0usize, 0usize);
     unsafe { nerf_abi_struct_sizes(&mut a, &mut b, &mut c) };
     let mine = (std::mem::size_of::<nerf_camera>(), std::mem::size_of::<nerf_render_opts>(), std::mem::size_of::<nerf_stats>());
-    if (a, b, c) == mine && unsafe { nerf_abi_version() } == 4 {
+    if (a, b, c) == mine && unsafe { nerf_abi_version() } == 5 {
         Ok(())
     } else {
-        Err(format!("libnerf_mi355x: ABI {} with struct sizes {:?}, this crate expects ABI 4 with {:?}", unsafe { nerf_abi_version() }, (a, b, c), mine))
+        Err(format!("libnerf_mi355x: ABI {} with struct sizes {:?}, this crate expects ABI 5 with {:?}", unsafe { nerf_abi_version() }, (a, b, c), mine))
     }
 }

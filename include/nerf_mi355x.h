@@ -100,13 +100,25 @@ typedef struct {
                            * found 0.9 unflagged rays per million beyond it, the largest at 2.8e-5.  Not bit-identical to
                            * hybrid_sampling = 0 (pixels differ by 2e-8 on average); held to the same Gate 1.
                            * nerf_stats.n_hybrid_rays = rays redone in f32. */
-    int32_t certify_zero;  /* ext (ABI 4; mlp_dtype F32, BF16X3 or F16X2, no skip mode): 1 = a bf16 pass over all samples finds those whose density
-                           * pre-activation is so far below 0 (coarse network: < -1, fine: < -2 -- several times the largest bf16-vs-f32
-                           * difference seen on such samples) that the f32 network's density is certainly 0 there as well; the f32
-                           * kernel -- for the fine pass of a split arithmetic that arithmetic's kernel -- then evaluates only the other
-                           * samples (a device-side list: 40 % of the coarse, 21 % of the fine samples of the lego frame).  A certified sample has sigma = 0, weight 0: the image is BIT-IDENTICAL to
-                           * certify_zero = 0 as long as no certificate is wrong (fuzzed: tools/fuzz_certify.py; the margins rest on
-                           * measurements, not on a proof -- hence opt-in).  nerf_stats.n_exec_* = samples the f32 kernel evaluated. */
+    int32_t certify_zero;  /* ext (ABI 4, reworked in ABI 5; mlp_dtype F32, BF16X3 or F16X2, no skip mode): 1 = a bf16 pass over all samples finds
+                           * (Z) the samples whose density pre-activation is so far below 0 (per-network margin, see below) that the exact
+                           * network's density is certainly 0 there as well, and predicts (C) where each ray's transmittance falls below the
+                           * reference's 1e-4 cut (src/lib.rs:276-279: every later weight is zero-filled whatever its density).  The exact kernel
+                           * -- for the fine pass of a split arithmetic that arithmetic's kernel -- evaluates only the other samples in front of
+                           * the predicted cut (a device-side list: 25-40 % of the coarse, 15-21 % of the fine samples of the lego frame); the
+                           * EXACT transmittance then confirms each cut, and where it does not (rare) the rest of that ray is evaluated in a
+                           * second launch -- so (C) is exact by construction.  A certified sample has sigma = 0, weight 0 (src/lib.rs:271-272):
+                           * the image is BIT-IDENTICAL to certify_zero = 0 as long as no certificate (Z) is wrong.
+                           * (Z) rests on measurements, not on a proof, so it is AUDITED in every frame: one certified sample in 64 is evaluated
+                           * exactly all the same; a positive density there (nerf_stats.n_certify_violations), or an audited sample on which the bf16
+                           * pass was off by more than half the margin (nerf_stats.certify_max_error, certify_headroom), widens that network's margin for the life of
+                           * the context (floors: 1.5 coarse, 3.0 fine -- 4-8 x the largest bf16-vs-f32 difference seen on zero-density samples of
+                           * the lego networks; reset when a network is loaded) and the frame is rendered again (nerf_stats.n_certify_retries); if
+                           * 8 widenings do not satisfy the audit the render fails with NERF_ERR_STATE.  A network on which bf16 is less accurate
+                           * thus calibrates itself, certifies nothing (random weights: pre-activations near 0), or fails loudly; what remains
+                           * unobserved is a wrong certificate that is so rare that a 1-in-64 audit of ~1e8 certified samples per frame never
+                           * meets one or its precursors.  Because of the audit a certify_zero render synchronises the stream before it returns
+                           * (also nerf_render_image_device with stats == NULL).  nerf_stats.n_exec_* = samples the exact kernel evaluated. */
 } nerf_render_opts;
 
 /* Device-side timing of the last render (HIP events on the render stream). */
@@ -127,7 +139,17 @@ typedef struct {
     uint64_t n_nonfinite_points;   /* split arithmetics: evaluations in which an operand left the arithmetic's range (NERF_MLP_F16X2: an
                                     * activation beyond 65 504 -- every value is watched as it is split, one v_max3 per pair) or whose density
                                     * pre-activation was not finite.  0 in every validated configuration; non-zero means the frame is WRONG
-                                    * there (f16 overflow yields finite garbage, not NaN).  nerf_forward_batch_ex fails with NERF_ERR_STATE. */
+                                    * there (f16 overflow yields finite garbage, not NaN): nerf_forward_batch_ex and every render that reads its
+                                    * counters (nerf_render_image, nerf_render_image_multi, nerf_render_image_device with stats != NULL) fail
+                                    * with NERF_ERR_STATE -- the stats are filled all the same. */
+    /* certify_zero (ABI 5): the audit of the frame that was returned, see nerf_render_opts.certify_zero */
+    uint64_t n_certify_audited;    /* certified samples that the exact kernel evaluated all the same (1 in 64) */
+    uint64_t n_certify_violations; /* audited samples whose exact density was positive, summed over ALL renders of this frame (the last one had none) */
+    uint32_t n_certify_retries;    /* times the frame was rendered again (margins widened after a failed audit, or the sample list enlarged) */
+    uint32_t n_certify_fallback_rays; /* rays whose predicted cut the exact transmittance did not confirm (their remaining samples went through a second launch) */
+    float certify_margin[2];       /* margins in force (coarse, fine network): a sample is certified iff its bf16 pre-activation < -margin */
+    float certify_headroom[2];     /* min over the audited samples of -(exact pre-activation): how far the closest one stood from a positive density (inf: none audited) */
+    float certify_max_error[2];    /* max over the audited samples of |bf16 - exact pre-activation|: what the bf16 pass got wrong on a sample it certified */
 } nerf_stats;
 
 /* ---- lifecycle ------------------------------------------------------------------------------------------ */
@@ -267,8 +289,9 @@ int nerf_stage_integrate(nerf_ctx *ctx, size_t n_rays, int n, float far_, const 
 /* "" for the product build.  Tuning / timing-only builds (make variant: some of their switches make results WRONG on purpose)
  * report "NAME: compile definitions"; a host should refuse such a library outside experiments (the Python loader does). */
 const char *nerf_build_variant(void);
-/* ABI version: bumped on any signature or struct change (2: multi-GPU entry points, skip_dead, n_exec_* statistics; 3: nerf_stats.
- * n_nonfinite_points, nerf_check_network_blob, nerf_stage_hybrid_flags, nerf_build_variant). */
+/* ABI version (currently 5): bumped on any signature or struct change (2: multi-GPU entry points, skip_dead, n_exec_* statistics; 3: nerf_stats.
+ * n_nonfinite_points, nerf_check_network_blob, nerf_stage_hybrid_flags, nerf_build_variant; 4: nerf_render_opts.certify_zero; 5: nerf_stats.
+ * n_certify_* / certify_margin / certify_headroom / certify_max_error, renders fail on n_nonfinite_points != 0). */
 int nerf_abi_version(void);
 /* sizeof(nerf_camera), sizeof(nerf_render_opts), sizeof(nerf_stats) as this library was built: lets a binding written in
  * another language (the Rust `-sys` crate, ctypes) check its struct mirrors at start-up. */

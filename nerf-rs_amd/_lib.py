@@ -36,7 +36,10 @@ class CStats(C.Structure):
                 ("ms_total", C.c_double), ("ms_coarse_mlp", C.c_double), ("ms_fine_mlp", C.c_double),
                 ("ms_other", C.c_double), ("n_mlp_launches", C.c_uint32), ("n_passes", C.c_uint32),
                 ("n_colour_skipped_points", C.c_uint64), ("n_exec_coarse_trunk", C.c_uint64), ("n_exec_fine_trunk", C.c_uint64),
-                ("n_exec_colour", C.c_uint64), ("n_hybrid_rays", C.c_uint64), ("n_nonfinite_points", C.c_uint64)]
+                ("n_exec_colour", C.c_uint64), ("n_hybrid_rays", C.c_uint64), ("n_nonfinite_points", C.c_uint64),
+                ("n_certify_audited", C.c_uint64), ("n_certify_violations", C.c_uint64), ("n_certify_retries", C.c_uint32),
+                ("n_certify_fallback_rays", C.c_uint32), ("certify_margin", C.c_float * 2), ("certify_headroom", C.c_float * 2),
+                ("certify_max_error", C.c_float * 2)]
 
 
 # name -> (restype, argtypes); kept in sync with include/nerf_mi355x.h (tests/test_host_logic.py::test_abi_exports_every_declared_symbol checks the header)

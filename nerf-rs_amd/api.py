@@ -32,7 +32,8 @@ def _p(a):
 class Stats:
     def __init__(self, c):
         for name, _ in CStats._fields_:
-            setattr(self, name, getattr(c, name))
+            v = getattr(c, name)
+            setattr(self, name, v if isinstance(v, (int, float)) else tuple(v))
 
     def __repr__(self):
         return "Stats(" + ", ".join(f"{k}={v}" for k, v in self.__dict__.items()) + ")"

@@ -176,18 +176,27 @@ __device__ __forceinline__ void rgb_head(const Tiles &V, const LDS_AS float *sma
 // look-ahead tile read the last point.
 struct RawIn { float a, b, c, dx, dy, dz; };
 
+// MLP_MODE_LIST: the list's length lives on the device; n_points is its CAPACITY (entries beyond it were counted, not stored: the host
+// renders such a frame again with a larger list, nerf_api.cpp)
+template <class Args>
+__device__ __forceinline__ int list_length(const Args &A) {
+    const unsigned n = *A.point_list_count;
+    return (int)(n < (unsigned)A.n_points ? n : (unsigned)A.n_points);
+}
+
 template <int MODE, class Args>
 __device__ __forceinline__ RawIn load_raw(const Args &A, int tile_idx, int wave, int p) {
     using namespace nerfmlp;
     RawIn r;
     int i = tile_idx * kPointsPerBlock + wave * kPointsPerWave + p;
-    if (MODE == 2) { // slot i of a device-side sample list (instantiated for the f32 kernel's MlpArgs only)
-        const int n = (int)*A.point_list_count;
+    if (MODE == 2) { // slot i of a device-side sample list: entry = sample index | (audited certificate ? 1 << 31 : 0)
+        const int n = list_length(A);
         r.a = 0.f; r.b = 0.f; r.c = 0.f; r.dx = 0.f; r.dy = 0.f; r.dz = 1.f;
         if (n <= 0) return r;
-        const unsigned idx = A.point_list[i < n ? i : n - 1];
+        const unsigned entry = A.point_list[i < n ? i : n - 1];
+        const unsigned idx = entry & 0x7fffffffu;
         const unsigned ray = idx / (unsigned)A.samples_per_ray;
-        r.a = A.t[idx]; r.b = __builtin_bit_cast(float, idx);
+        r.a = A.t[idx]; r.b = __builtin_bit_cast(float, entry);
         r.dx = A.ray_dirs[3 * (size_t)ray]; r.dy = A.ray_dirs[3 * (size_t)ray + 1]; r.dz = A.ray_dirs[3 * (size_t)ray + 2];
         return r;
     }

@@ -257,8 +257,8 @@ __device__ __forceinline__ void hidden_layer(const f32x16 (&in)[8], f32x16 (&out
     for (int t = 0; t < 8; ++t) tile_steps<8, RELU>(in[t], out, P);
 }
 
-// alpha head on the VALU: sigma = relu(b + sum_F w[F] relu(h8[F]))  (src/network.rs:216)
-__device__ __forceinline__ float alpha_head(const f32x16 (&Y)[8], const LDS_AS float *small, int h) {
+// alpha head on the VALU: sigma = relu(b + sum_F w[F] relu(h8[F]))  (src/network.rs:216); alpha_pre = the value inside the relu
+__device__ __forceinline__ float alpha_pre(const f32x16 (&Y)[8], const LDS_AS float *small, int h) {
     const LDS_AS f32x4 *w = (const LDS_AS f32x4 *)(small + kAlphaWOff + h * 128);
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
 #pragma unroll
@@ -272,7 +272,9 @@ __device__ __forceinline__ float alpha_head(const f32x16 (&Y)[8], const LDS_AS f
             a3 = fmaf(wv[3], relu(Y[t][4 * q + 3]), a3);
         }
     }
-    return fmaxf(xhalf_sum((a0 + a1) + (a2 + a3)) + small[kMiscOff + 0], 0.f);
+    return xhalf_sum((a0 + a1) + (a2 + a3)) + small[kMiscOff + 0];
 }
+
+__device__ __forceinline__ float alpha_head(const f32x16 (&Y)[8], const LDS_AS float *small, int h) { return fmaxf(alpha_pre(Y, small, h), 0.f); }
 
 } // namespace mlpf32

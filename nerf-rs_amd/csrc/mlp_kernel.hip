@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256, 1) void nerf_mlp_kernel(const MlpArgs A) {
         P.nx[2 * j + 1] = *(const LDS_AS f32x4 *)(P.rd_base + j * 2048 + 1024);
     }
 
-    const int n_points = MODE == MLP_MODE_LIST ? (int)*A.point_list_count : A.n_points; // list mode: the length lives on the device
+    const int n_points = MODE == MLP_MODE_LIST ? list_length(A) : A.n_points; // list mode: the length lives on the device
     const int n_tiles = (n_points + kPointsPerBlock - 1) / kPointsPerBlock;
 #if NERF_PREFETCH_INPUTS
     RawIn nxt = load_raw<MODE>(A, blockIdx.x, wave, p);
@@ -84,7 +84,10 @@ __global__ __launch_bounds__(256, 1) void nerf_mlp_kernel(const MlpArgs A) {
         float px, py, pz;
         point_of<MODE>(A, in, px, py, pz);
         const float dx = in.dx, dy = in.dy, dz = in.dz;
-        const size_t i = MODE == MLP_MODE_LIST ? (size_t)__builtin_bit_cast(unsigned, in.b) : (size_t)slot; // where the outputs go
+        const unsigned entry = __builtin_bit_cast(unsigned, in.b);
+        const size_t i = MODE == MLP_MODE_LIST ? (size_t)(entry & 0x7fffffffu) : (size_t)slot; // where the outputs go
+        // an audited certificate (certify_zero): the raw pre-activation leaves the kernel -- k_cert_audit compares it with 0
+        const bool audit = MODE == MLP_MODE_LIST && (entry >> 31) != 0;
 
         f32x16 E[2];
         encode_point<NERF_FAST_SINCOS != 0>(px, py, pz, h, E);
@@ -111,8 +114,9 @@ __global__ __launch_bounds__(256, 1) void nerf_mlp_kernel(const MlpArgs A) {
         // dense6, dense7
         hidden_layer<true>(Y, X, small + kBiasOff + 6 * 256, P, h);
         hidden_layer<true>(X, Y, small + kBiasOff + 7 * 256, P, h);
-        sigma = alpha_head(Y, small, h);
-        if (valid && h == 0) A.sigma_out[i] = sigma;
+        const float pre = alpha_pre(Y, small, h);
+        sigma = fmaxf(pre, 0.f);
+        if (valid && h == 0) A.sigma_out[i] = audit ? pre : sigma;
         if (FULL && A.skip_empty) {
             // Empty-tile skip (exact): if sigma == 0 for all 128 points of this workgroup's tile, then
             // alpha = 1 - exp(-0 * delta) = 0 and w = T * 0 = 0 exactly for each of them (src/lib.rs:271-272), so their

@@ -70,7 +70,7 @@ __device__ __forceinline__ void hidden_layer(f32x16 (&in)[8], f32x16 (&out)[8], 
 // the f16 range splits into (inf, -inf) and turns into NaN in the next layer; fmaxf below would silently return 0 for it.  One v_cmp
 // per tile makes that observable (nerf_stats.n_nonfinite_points; nerf_forward_batch_ex fails with NERF_ERR_STATE).
 constexpr float kUncertainZeroMargin = 4e-5f; // 2 x the absolute part of k_resample's density-error bound (sampling_kernels.hip)
-__device__ __forceinline__ float alpha_head(const f32x16 (&Y)[8], const LDS_AS float *small, int h, unsigned int *nonfinite, bool valid) {
+__device__ __forceinline__ float alpha_head(const f32x16 (&Y)[8], const LDS_AS float *small, int h, unsigned int *nonfinite, bool valid, float *pre_out = nullptr) {
     const LDS_AS f32x4 *w = (const LDS_AS f32x4 *)(small + kAlphaWOff + h * 128);
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
 #pragma unroll
@@ -87,6 +87,7 @@ __device__ __forceinline__ float alpha_head(const f32x16 (&Y)[8], const LDS_AS f
         }
     }
     const float pre = xhalf_sum((a0 + a1) + (a2 + a3)) + small[kMiscOff + 0];
+    if (pre_out) *pre_out = pre;
     if (nonfinite) {
         const unsigned long long bad = __ballot(valid && !(fabsf(pre) <= 3.0e38f)) & 0xffffffffull; // one lane-half per point
         if (bad && (threadIdx.x & 63) == 0) atomicAdd(nonfinite, (unsigned)__popcll(bad));
@@ -127,7 +128,7 @@ __global__ __launch_bounds__(256, 1) void SPLIT_KERNEL_FUSED(const MlpArgs A) {
     uint64_t clk0 = 0, rt0 = 0;
     if (A.clock_out) { clk0 = __builtin_amdgcn_s_memtime(); rt0 = __builtin_amdgcn_s_memrealtime(); }
 
-    const int n_points = MODE == MLP_MODE_LIST ? (int)*A.point_list_count : A.n_points; // list mode (certify_zero): the length lives on the device
+    const int n_points = MODE == MLP_MODE_LIST ? list_length(A) : A.n_points; // list mode (certify_zero): the length lives on the device
     const int n_tiles = (n_points + kPointsPerBlock - 1) / kPointsPerBlock;
     RawIn nxt = load_raw<MODE>(A, blockIdx.x, wave, p);
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
@@ -138,7 +139,9 @@ __global__ __launch_bounds__(256, 1) void SPLIT_KERNEL_FUSED(const MlpArgs A) {
         float px, py, pz;
         point_of<MODE>(A, in, px, py, pz);
         const float dx = in.dx, dy = in.dy, dz = in.dz;
-        const size_t i = MODE == MLP_MODE_LIST ? (size_t)__builtin_bit_cast(unsigned, in.b) : (size_t)slot; // where the outputs go
+        const unsigned entry = __builtin_bit_cast(unsigned, in.b);
+        const size_t i = MODE == MLP_MODE_LIST ? (size_t)(entry & 0x7fffffffu) : (size_t)slot; // where the outputs go
+        const bool audit = MODE == MLP_MODE_LIST && (entry >> 31) != 0; // an audited certificate: the raw pre-activation leaves the kernel (k_cert_audit)
 
         f32x16 E[2];
         encode_point<true>(px, py, pz, h, E);
@@ -162,8 +165,9 @@ __global__ __launch_bounds__(256, 1) void SPLIT_KERNEL_FUSED(const MlpArgs A) {
         hidden_layer<true>(Y, X, small + kBiasOff + 6 * 256, P, h);
         hidden_layer<true>(X, Y, small + kBiasOff + 7 * 256, P, h);
 
-        const float sigma = alpha_head(Y, small, h, A.nonfinite, valid);
-        if (valid && h == 0) A.sigma_out[i] = sigma;
+        float pre;
+        const float sigma = alpha_head(Y, small, h, A.nonfinite, valid, &pre);
+        if (valid && h == 0) A.sigma_out[i] = audit ? pre : sigma;
         if (!FULL) range_check(P, A.nonfinite, valid);
 
         if (FULL && A.skip_empty) { // exact empty-tile skip, see mlp_kernel.hip

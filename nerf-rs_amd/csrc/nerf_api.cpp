@@ -285,6 +285,7 @@ int upload_packed(nerf_ctx *c, int which, const std::vector<float> &ws, const st
     HIP_TRY(c, hipMemcpy(d.wstream, ws.data(), ws.size() * sizeof(float), hipMemcpyHostToDevice));
     HIP_TRY(c, hipMemcpy(d.small, sm.data(), sm.size() * sizeof(float), hipMemcpyHostToDevice));
     d.loaded = true;
+    c->cert_margin[which] = c->cert_margin_floor[which]; // certify_zero calibrates itself per network
     return NERF_OK;
 }
 
@@ -322,10 +323,21 @@ struct Timed {
     }
 };
 
-} // namespace
+// What the audit of a certify_zero frame found (per network: 0 coarse, 1 fine), read from the device after the frame.
+struct CertOutcome {
+    uint64_t audited[2] = {0, 0}, violations[2] = {0, 0};
+    float headroom[2] = {INFINITY, INFINITY}; // min over the audited certificates of -(exact pre-activation)
+    float max_err[2] = {0.0f, 0.0f};          // max over them of |bf16 - exact pre-activation|
+    uint64_t listed[2] = {0, 0};      // samples the exact kernel evaluated (both launches, audited certificates included)
+    uint64_t fallback_rays = 0;       // rays whose predicted cut the exact transmittance did not confirm
+    uint64_t list_need = 0;           // largest list any pass wanted ...
+    uint64_t list_capacity = 0;       // ... and what it had
+    uint64_t pass_samples = 0;        // samples of the largest network pass (the list's worst case)
+    bool used[2] = {false, false};
+};
 
-int nerfint::render_device(nerf_ctx *c, const nerf_camera *cam, const nerf_render_opts *o, float *d_out, hipStream_t st,
-                           nerf_stats *stats) {
+int render_once(nerf_ctx *c, const nerf_camera *cam, const nerf_render_opts *o, float *d_out, hipStream_t st, nerf_stats *stats,
+                CertOutcome *cert) {
     int rc;
     if ((rc = check_camera(c, cam))) return rc;
     if (!o) return fail(c, NERF_ERR_INVALID, "opts is NULL");
@@ -429,20 +441,33 @@ int nerfint::render_device(nerf_ctx *c, const nerf_camera *cam, const nerf_rende
         }
         if (hybrid && (rc = ensure_bytes(c, (void **)&c->d_flag_list, &c->flag_list_bytes, rows_per_pass * RW * sizeof(unsigned int)))) return rc;
     }
-    // Zero certification (nerf_render_opts.certify_zero; f32 renders without skip modes): a bf16 pass over all samples finds the
-    // ones whose density pre-activation is so far below 0 (coarse: < -1, fine: < -2; NERF_CERTIFY_MARGINS="c,f") that the f32 network's
-    // density is certainly 0 there too -- several times the largest bf16-vs-f32 difference seen on such samples -- and the f32 kernel
-    // evaluates only the rest (a device-side list).  A certified sample has sigma = 0 => weight 0: the frame is the f32 frame, bit for bit,
-    // as long as no certificate is wrong.  DESIGN 9.
-    float cert_margin[2] = {1.0f, 2.0f};
-    bool certify = false;
-    certify = o->certify_zero != 0;
+    // Zero certification (nerf_render_opts.certify_zero; DESIGN 4.9, protocol: sampling_kernels.hip k_cert_*): a bf16 pass over all samples
+    // finds (Z) the samples whose density pre-activation is so far below 0 (margin per network, c->cert_margin: audited every frame and
+    // widened by render_device when the audit's headroom shrinks) that the exact network's density is certainly 0 there too, and predicts
+    // (C) where each ray's transmittance falls below the reference's 1e-4 cut; the exact kernel evaluates only the remaining samples in
+    // front of the predicted cut (a device-side list), the exact transmittance confirms the cut (or a second launch evaluates the rest).
+    // A certified sample has sigma = 0 => weight 0, a sample behind the cut has weight 0 whatever its density: the frame is the plain
+    // frame, bit for bit, as long as no certificate is wrong.
+    const bool certify = o->certify_zero != 0;
+    constexpr int kCertSlots = 8; // per (pass, network): {list 1 length, list 2 length, audited, violations, headroom code, max-error bits, fallback rays, audit-record count}
+    size_t aux_cap = 0;
+    size_t cert_cap = 0;
     if (certify) {
-        if (const char *env = getenv("NERF_CERTIFY_MARGINS")) (void)sscanf(env, "%f,%f", &cert_margin[0], &cert_margin[1]);
+        if (cert_plan_lds_bytes(M, nullptr) > 160 * 1024) return fail(c, NERF_ERR_INVALID, "certify_zero: too many samples per ray");
         const size_t n_pass = ((size_t)RH + rows_per_pass - 1) / rows_per_pass;
-        if ((rc = ensure_bytes(c, (void **)&c->d_point_list, &c->point_list_bytes, rows_per_pass * RW * (size_t)M * sizeof(unsigned int)))) return rc;
-        if ((rc = ensure_bytes(c, (void **)&c->d_cert, &c->cert_bytes, 2 * n_pass * sizeof(unsigned int)))) return rc;
-        HIP_TRY(c, hipMemsetAsync(c->d_cert, 0, 2 * n_pass * sizeof(unsigned int), st));
+        const size_t pass_samples = rows_per_pass * RW * (size_t)M;
+        // the list is sized from what earlier frames needed (c->cert_list_frac of the samples, +25 %): if a pass wants more, the entries
+        // beyond the capacity are counted, not stored, and render_device renders the frame again with a list that fits
+        // (up to 64 MiB the list simply holds every sample: small renders -- a central crop lists 70 % of its samples -- never take that path)
+        cert_cap = pass_samples <= ((size_t)16 << 20) ? pass_samples : std::min<size_t>(pass_samples, (size_t)((double)pass_samples * c->cert_list_frac) + 4096);
+        if ((rc = ensure_bytes(c, (void **)&c->d_point_list, &c->point_list_bytes, cert_cap * sizeof(unsigned int)))) return rc;
+        cert_cap = std::min<size_t>(pass_samples, c->point_list_bytes / sizeof(unsigned int)); // an earlier, larger allocation is kept
+        if ((rc = ensure_bytes(c, (void **)&c->d_jstar, &c->jstar_bytes, rows_per_pass * RW * sizeof(int)))) return rc;
+        aux_cap = 2 * (pass_samples / ((size_t)c->cert_audit_mask + 1)) + 4096; // twice the expected number of audited certificates: one that does not fit is not audited
+        if ((rc = ensure_bytes(c, (void **)&c->d_cert_aux, &c->cert_aux_bytes, aux_cap * 2 * sizeof(unsigned int)))) return rc;
+        if ((rc = ensure_bytes(c, (void **)&c->d_cert, &c->cert_bytes, kCertSlots * 2 * n_pass * sizeof(unsigned int)))) return rc;
+        HIP_TRY(c, hipMemsetAsync(c->d_cert, 0, kCertSlots * 2 * n_pass * sizeof(unsigned int), st));
+        if (cert) { cert->list_capacity = cert_cap; cert->pass_samples = pass_samples; }
     }
     recycle_render(c);
     recycle_dominant(c, 4096); // bound the backlog if the caller never queries
@@ -506,26 +531,47 @@ int nerfint::render_device(nerf_ctx *c, const nerf_camera *cam, const nerf_rende
         a.mode = MLP_MODE_RAYS;
         a.ray_dirs = c->d_dirs;
         a.origin[0] = cam->pos[0]; a.origin[1] = cam->pos[1]; a.origin[2] = cam->pos[2];
-        // zero certification: bf16 pre-activations of all samples -> list of the samples that are not certain zeros -> f32 kernel on the list
+        // zero certification: bf16 pre-activations of all samples -> plan (list 1, predicted cuts) -> exact kernel on list 1 -> audit ->
+        // exact transmittance confirms the cuts (list 2 = what is left of the rays it does not) -> exact kernel on list 2
         auto cert_pass = [&](const DevNet &net, int which, int dt, int spr, const float *t_in, float *sigma_out, float *rgb_out, int kind) -> int {
             const int n_pts = n_rays * spr;
-            unsigned int *cnt = c->d_cert + 2 * (size_t)passes + which;
+            unsigned int *slots = c->d_cert + kCertSlots * (2 * (size_t)passes + which);
+            const unsigned cap = (unsigned)std::min<size_t>(cert_cap, (size_t)n_pts);
             MlpArgs b = a;
             b.wstream = stream_of(net, NERF_MLP_BF16); b.small_params = net.small; b.n_points = n_pts; b.samples_per_ray = spr; b.t = t_in;
-            b.sigma_out = sigma_out; b.rgb_out = nullptr; b.raw_pre = 1;
+            b.sigma_out = sigma_out; b.rgb_out = nullptr; b.raw_pre = 1; b.skip_empty = 0; b.skip_counter = nullptr; b.nonfinite = nullptr;
+            const int kind_side = which == 0 && !rgb_out ? 0 : 4;
             {
-                Timed t(c, st, which == 0 && !rgb_out ? 0 : 4, 0, timing);
+                Timed t(c, st, kind_side, 0, timing);
                 HIP_TRY(c, launch_mlp(c, NERF_MLP_BF16, b, false, st));
-                HIP_TRY(c, launch_uncertain_list(sigma_out, n_pts, cert_margin[which], c->d_point_list, cnt, st));
-                if (rgb_out) HIP_TRY(c, hipMemsetAsync(rgb_out, 0, (size_t)n_pts * 3 * sizeof(float), st)); // a certain zero has weight 0: 0 * 0
+                CertPlanArgs p{};
+                p.pre = sigma_out; p.t = t_in; p.n_rays = n_rays; p.spr = spr; p.far_ = cam->far_;
+                p.margin = c->cert_margin[which]; p.depth_limit = c->cert_depth_limit;
+                p.audit_mask = c->cert_audit_mask; p.audit_salt = (unsigned)(o->seed * 0x9E3779B97F4A7C15ull >> 32) + 0x632BE5ABu * passes + (unsigned)which;
+                p.list = c->d_point_list; p.count = slots; p.capacity = cap; p.jstar = c->d_jstar;
+                p.aux = c->d_cert_aux; p.aux_count = slots + 7; p.aux_capacity = (unsigned)aux_cap;
+                HIP_TRY(c, launch_cert_plan(p, st));
+                if (rgb_out) HIP_TRY(c, hipMemsetAsync(rgb_out, 0, (size_t)n_pts * 3 * sizeof(float), st)); // weight 0 either way: 0 * 0
                 t.done(c->last_render);
             }
             MlpArgs l = b;
-            l.wstream = stream_of(net, dt); l.raw_pre = 0; l.mode = MLP_MODE_LIST; l.rgb_out = rgb_out;
-            l.point_list = c->d_point_list; l.point_list_count = cnt;
+            l.wstream = stream_of(net, dt); l.raw_pre = 0; l.mode = MLP_MODE_LIST; l.rgb_out = rgb_out; l.n_points = (int)cap;
+            l.point_list = c->d_point_list; l.point_list_count = slots;
             l.nonfinite = split_dtype(dt) ? c->d_nonfinite : nullptr;
-            Timed t(c, st, kind, (uint64_t)n_pts, timing);
-            HIP_TRY(c, launch_mlp(c, dt, l, rgb_out != nullptr, st));
+            if (cap > 0) {
+                // points = 0: the list's length is known on the device only (nerf_stats.n_exec_* report it after the frame)
+                Timed t(c, st, kind, 0, timing);
+                HIP_TRY(c, launch_mlp(c, dt, l, rgb_out != nullptr, st));
+                t.done(c->last_render);
+            }
+            Timed t(c, st, kind_side, 0, timing);
+            HIP_TRY(c, launch_cert_audit(c->d_cert_aux, slots + 7, (unsigned)aux_cap, sigma_out, slots + 2, c->n_cus, st));
+            CertVerifyArgs v{};
+            v.t = t_in; v.sigma = sigma_out; v.n_rays = n_rays; v.spr = spr; v.far_ = cam->far_; v.jstar = c->d_jstar;
+            v.list = c->d_point_list; v.count = slots + 1; v.capacity = cap; v.fallback_rays = slots + 6;
+            HIP_TRY(c, launch_cert_verify(v, st));
+            l.point_list_count = slots + 1;
+            if (cap > 0) HIP_TRY(c, launch_mlp(c, dt, l, rgb_out != nullptr, st)); // usually an empty list: the launch returns at once
             t.done(c->last_render);
             return NERF_OK;
         };
@@ -622,19 +668,41 @@ int nerfint::render_device(nerf_ctx *c, const nerf_camera *cam, const nerf_rende
     for (const auto &p : c->last_render)
         if (p.kind == 1) c->dominant.push_back(p);
     scope.ok = true;
+    if (cert) { // the audit's outcome decides whether this frame stands (render_device): certify_zero renders synchronise the stream
+        HIP_TRY(c, hipStreamSynchronize(st));
+        std::vector<unsigned int> h((size_t)passes * 2 * kCertSlots);
+        HIP_TRY(c, hipMemcpy(h.data(), c->d_cert, h.size() * sizeof(unsigned int), hipMemcpyDeviceToHost));
+        for (uint32_t k = 0; k < passes * 2; ++k) {
+            const unsigned int *q = &h[(size_t)k * kCertSlots];
+            const int w = (int)(k & 1);
+            if (w == 1 && o->coarse_only) continue;
+            cert->used[w] = true;
+            cert->listed[w] += std::min<uint64_t>(q[0], cert->list_capacity) + std::min<uint64_t>(q[1], cert->list_capacity);
+            cert->list_need = std::max<uint64_t>(cert->list_need, std::max(q[0], q[1]));
+            cert->audited[w] += q[2]; cert->violations[w] += q[3];
+            if (q[2]) {
+                const unsigned bits = 0x7f800000u - q[4];
+                float hr, er;
+                memcpy(&hr, &bits, sizeof hr); memcpy(&er, &q[5], sizeof er);
+                cert->headroom[w] = std::min(cert->headroom[w], hr); cert->max_err[w] = std::max(cert->max_err[w], er);
+            }
+            cert->fallback_rays += q[6];
+        }
+    }
     if (stats) {
         HIP_TRY(c, hipStreamSynchronize(st));
         memset(stats, 0, sizeof *stats);
         stats->n_rays = (uint64_t)RW * RH;
         stats->n_passes = passes;
+        stats->n_coarse_points = stats->n_rays * (uint64_t)nc;                       // nominal: every sample of every ray
+        stats->n_fine_points = o->coarse_only ? 0 : stats->n_rays * (uint64_t)M;
         for (const auto &p : c->last_render) {
             float ms = 0.f;
             HIP_TRY(c, hipEventElapsedTime(&ms, p.a, p.b));
-            if (p.kind == 0) { stats->ms_coarse_mlp += ms; stats->n_coarse_points += p.points; stats->n_mlp_launches++; }
+            if (p.kind == 0) { stats->ms_coarse_mlp += ms; stats->n_mlp_launches++; }
             else if (p.kind == 1) {
                 stats->n_mlp_launches++;
-                if (o->coarse_only) { stats->ms_coarse_mlp += ms; stats->n_coarse_points += p.points; }
-                else { stats->ms_fine_mlp += ms; stats->n_fine_points += p.points; }
+                if (o->coarse_only) stats->ms_coarse_mlp += ms; else stats->ms_fine_mlp += ms;
             } else if (p.kind == 4) { // colour head on the compacted live samples (skip_dead)
                 stats->n_mlp_launches++;
                 if (o->coarse_only) stats->ms_coarse_mlp += ms; else stats->ms_fine_mlp += ms;
@@ -659,14 +727,14 @@ int nerfint::render_device(nerf_ctx *c, const nerf_camera *cam, const nerf_rende
         stats->n_exec_coarse_trunk = stats->n_coarse_points;
         stats->n_exec_fine_trunk = stats->n_fine_points;
         stats->n_exec_colour = (o->coarse_only ? stats->n_coarse_points : stats->n_fine_points) - stats->n_colour_skipped_points;
-        if (certify) { // samples the f32 kernel evaluated = the lengths of the lists
-            std::vector<unsigned int> h((size_t)passes * 2);
-            HIP_TRY(c, hipMemcpy(h.data(), c->d_cert, h.size() * sizeof(unsigned int), hipMemcpyDeviceToHost));
-            uint64_t n0 = 0, n1 = 0;
-            for (uint32_t k = 0; k < passes; ++k) { n0 += h[2 * (size_t)k]; n1 += h[2 * (size_t)k + 1]; }
-            stats->n_exec_coarse_trunk = n0;
-            stats->n_exec_fine_trunk = o->coarse_only ? 0 : n1;
-            stats->n_exec_colour = o->coarse_only ? n0 : n1;
+        if (certify && cert) { // samples the exact kernel evaluated = the lengths of the lists (audited certificates included)
+            stats->n_exec_coarse_trunk = cert->listed[0];
+            stats->n_exec_fine_trunk = o->coarse_only ? 0 : cert->listed[1];
+            stats->n_exec_colour = o->coarse_only ? cert->listed[0] : cert->listed[1];
+            stats->n_certify_audited = cert->audited[0] + cert->audited[1];
+            stats->n_certify_violations = cert->violations[0] + cert->violations[1];
+            stats->n_certify_fallback_rays = (uint32_t)std::min<uint64_t>(cert->fallback_rays, 0xffffffffu);
+            for (int w = 0; w < 2; ++w) { stats->certify_margin[w] = c->cert_margin[w]; stats->certify_headroom[w] = cert->headroom[w]; stats->certify_max_error[w] = cert->max_err[w]; }
         }
         if (seq) {
             std::vector<unsigned int> h((size_t)passes * 3 * 4);
@@ -684,8 +752,60 @@ int nerfint::render_device(nerf_ctx *c, const nerf_camera *cam, const nerf_rende
             stats->n_exec_colour = live;
             stats->n_colour_skipped_points = (o->coarse_only ? stats->n_coarse_points : stats->n_fine_points) - live;
         }
+        if (stats->n_nonfinite_points) { // the frame is WRONG there (f16 overflow yields finite garbage, not NaN): never return it as a success
+            char msg[320];
+            snprintf(msg, sizeof msg, "%llu evaluations: an operand left the range of the split arithmetic (NERF_MLP_F16X2: |activation| <= 65504) or a "
+                     "density was not finite; the frame is not usable -- use NERF_MLP_BF16X3 or NERF_MLP_F32", (unsigned long long)stats->n_nonfinite_points);
+            return fail(c, NERF_ERR_STATE, msg);
+        }
     }
     return NERF_OK;
+}
+
+} // namespace
+
+// certify_zero frames are AUDITED (k_cert_audit: one certified sample in 64 is evaluated exactly all the same).  A frame stands only if no
+// audited certificate was wrong and the closest audited sample kept at least half the margin between itself and a positive density;
+// otherwise the network's margin is widened -- for good: c->cert_margin is per context and network, reset when a network is loaded --
+// and the frame is rendered again.  The same loop grows the sample list when a pass wanted more entries than it had.  Margins are
+// measurements, not proofs: what this buys is that a network on which bf16 is less accurate than on the lego scene
+// calibrates itself or fails loudly (NERF_ERR_STATE) instead of returning a silently different frame.
+int nerfint::render_device(nerf_ctx *c, const nerf_camera *cam, const nerf_render_opts *o, float *d_out, hipStream_t st,
+                           nerf_stats *stats) {
+    if (!o || !o->certify_zero) return render_once(c, cam, o, d_out, st, stats, nullptr);
+    constexpr int kMaxRetries = 8;
+    uint64_t violations = 0;
+    for (int attempt = 0;; ++attempt) {
+        CertOutcome oc;
+        const int rc = render_once(c, cam, o, d_out, st, stats, &oc);
+        if (rc) return rc;
+        bool again = false;
+        std::string why;
+        if (oc.list_need > oc.list_capacity) { // (entries beyond the capacity were counted, not stored)
+            c->cert_list_frac = std::min(1.0, 1.25 * (double)oc.list_need / (double)std::max<uint64_t>(oc.pass_samples, 1));
+            again = true;
+            why = "the sample list was too short";
+        }
+        const bool overflow = again; // an attempt whose list was too short evaluated only a part of it: its audit says nothing
+        if (!overflow) violations += oc.violations[0] + oc.violations[1];
+        for (int w = 0; w < 2 && !overflow; ++w) {
+            if (!oc.used[w] || !oc.audited[w]) continue;
+            const float m = c->cert_margin[w];
+            // what the bf16 pass got wrong on the samples it certified, as far as the audit saw: at the margin (m - headroom) and anywhere below it
+            const float err = std::max(oc.max_err[w], m - oc.headroom[w]);
+            if (oc.violations[w]) { c->cert_margin[w] = std::max(4.0f * m, 4.0f * err); again = true; why = "an audited certificate was wrong"; }
+            else if (!(oc.headroom[w] >= 0.5f * m)) { c->cert_margin[w] = std::max(2.0f * m, 4.0f * err); again = true; why = "an audited certificate came closer to a positive density than half the margin"; }
+            else if (!(err <= 0.5f * m)) { c->cert_margin[w] = std::max(1.25f * m, 3.0f * err); again = true; why = "the bf16 pass was off by more than half the margin on an audited certificate"; }
+        }
+        if (stats) { stats->n_certify_retries = (uint32_t)attempt; stats->n_certify_violations = violations; }
+        if (!again) return NERF_OK;
+        if (attempt == kMaxRetries) {
+            char msg[320];
+            snprintf(msg, sizeof msg, "certify_zero: %s after %d renders of this frame (margins now %g / %g): the bf16 pass cannot certify this network's "
+                     "zero densities; render with certify_zero = 0", why.c_str(), attempt + 1, (double)c->cert_margin[0], (double)c->cert_margin[1]);
+            return fail(c, NERF_ERR_STATE, msg);
+        }
+    }
 }
 
 // ================================================================================================
@@ -699,7 +819,7 @@ int nerfint::render_device(nerf_ctx *c, const nerf_camera *cam, const nerf_rende
 
 extern "C" {
 
-int nerf_abi_version(void) { return 4; }
+int nerf_abi_version(void) { return 5; }
 
 void nerf_abi_struct_sizes(size_t *camera, size_t *render_opts, size_t *stats) {
     if (camera) *camera = sizeof(nerf_camera);
@@ -739,6 +859,14 @@ int nerf_create(int device_id, nerf_ctx **out) try {
         const double v = atof(env);
         if (v >= 0.0 && v <= 1.0) c->hybrid_tau = (float)v;
     }
+#ifdef NERF_CERT_TUNING // variant builds only (make variant DEFS=-DNERF_CERT_TUNING=1): the product's certificates are not configurable from the environment
+    if (const char *env = getenv("NERF_CERTIFY_CUT_DEPTH")) { const double v = atof(env); if (v > 0.0) c->cert_depth_limit = (float)v; }
+    if (const char *env = getenv("NERF_CERTIFY_AUDIT_MASK")) { const long v = atol(env); if (v >= 0 && ((v + 1) & v) == 0) c->cert_audit_mask = (unsigned)v; }
+    if (const char *env = getenv("NERF_CERTIFY_MARGINS")) {
+        float m0 = 0.f, m1 = 0.f;
+        if (sscanf(env, "%f,%f", &m0, &m1) == 2 && m0 > 0.f && m1 > 0.f) { c->cert_margin_floor[0] = m0; c->cert_margin_floor[1] = m1; c->cert_margin[0] = m0; c->cert_margin[1] = m1; }
+    }
+#endif
     if (const char *env = getenv("NERF_DEBUG_CLOCK")) {
         if (atoi(env) > 0 && hipMalloc((void **)&c->d_clock, (size_t)c->n_cus * 2 * sizeof(unsigned long long)) != hipSuccess) c->d_clock = nullptr;
     }
@@ -792,6 +920,8 @@ void nerf_destroy(nerf_ctx *c) {
     if (c->d_slot_point) (void)hipFree(c->d_slot_point);
     if (c->d_flag_list) (void)hipFree(c->d_flag_list);
     if (c->d_point_list) (void)hipFree(c->d_point_list);
+    if (c->d_jstar) (void)hipFree(c->d_jstar);
+    if (c->d_cert_aux) (void)hipFree(c->d_cert_aux);
     if (c->d_cert) (void)hipFree(c->d_cert);
     recycle_render(c);
     recycle_dominant(c, 0);
@@ -939,7 +1069,8 @@ int nerf_render_image(nerf_ctx *c, const nerf_camera *cam, const nerf_render_opt
     if (w <= 0 || h <= 0) return fail(c, NERF_ERR_INVALID, "crop window outside the frame");
     const size_t bytes = (size_t)w * h * 3 * sizeof(float);
     if ((rc = ensure_bytes(c, (void **)&c->d_out, &c->out_floats, bytes))) return rc;
-    if ((rc = render_device(c, cam, opts, c->d_out, c->stream, stats))) return rc;
+    nerf_stats local; // a synchronous render always reads its counters: a frame computed outside a split arithmetic's range is an error
+    if ((rc = render_device(c, cam, opts, c->d_out, c->stream, stats ? stats : &local))) return rc;
     HIP_TRY(c, hipMemcpyAsync(rgb_out, c->d_out, bytes, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return NERF_OK;

@@ -20,6 +20,10 @@ struct DevNet {
     bool loaded = false;
 };
 
+// certify_zero: a sample is a certain zero iff its bf16 density pre-activation is below -margin.  Floors per network (lego: the largest
+// bf16-vs-f32 difference seen on true zeros is 0.18 coarse / 0.72 fine; round 3 shipped 1 / 2, the fuzz first failed at a quarter of that).
+constexpr float kCertMarginCoarse = 1.5f, kCertMarginFine = 3.0f;
+
 struct EvPair {
     hipEvent_t a, b;
     int kind; // 0 coarse mlp, 1 fine mlp (dominant), 2 other
@@ -49,8 +53,17 @@ struct nerf_ctx {
     float *d_h8 = nullptr; size_t h8_bytes = 0;
     unsigned int *d_slot_point = nullptr; size_t slot_point_bytes = 0;
     unsigned int *d_flag_list = nullptr; size_t flag_list_bytes = 0; // hybrid sampling: rays whose coarse pass is redone in f32
-    unsigned int *d_point_list = nullptr; size_t point_list_bytes = 0; // zero certification (experimental): samples the f32 kernel evaluates
-    unsigned int *d_cert = nullptr; size_t cert_bytes = 0;             // ... and their counts: [2 * pass + (0 coarse | 1 fine)]
+    // zero certification (nerf_render_opts.certify_zero; nerf_api.cpp cert_pass, sampling_kernels.hip k_cert_*)
+    unsigned int *d_point_list = nullptr; size_t point_list_bytes = 0; // samples the exact kernel evaluates (one list, reused by every launch)
+    unsigned int *d_cert = nullptr; size_t cert_bytes = 0;             // counters, 8 per (pass, network)
+    int *d_jstar = nullptr; size_t jstar_bytes = 0;                    // per ray of a pass: first sample behind the predicted cut
+    unsigned int *d_cert_aux = nullptr; size_t cert_aux_bytes = 0;     // {sample, bf16 pre-activation} of the audited certificates of a launch
+    float cert_margin[2] = {nerfint::kCertMarginCoarse, nerfint::kCertMarginFine}; // widened by render_device when an audit fails; reset at load
+    float cert_margin_floor[2] = {nerfint::kCertMarginCoarse, nerfint::kCertMarginFine};
+    float cert_depth_limit = 9.6f;        // predicted cut: bf16 optical depth > 9.6 (the exact cut is at T < 1e-4 = depth 9.21; nothing but work depends on it:
+                                          // lego frame 0 rays fall back at 9.5, 25 at 9.35, 1132 of 640 000 at 9.25 -- tools/sweep_certify.py)
+    unsigned cert_audit_mask = 63;        // one certified sample in 64 is audited
+    double cert_list_frac = 0.5;          // list capacity as a fraction of a pass's samples: what earlier frames needed + 25 %
     float hybrid_tau = 1e-5f;                                        // a draw predicted to move by more than this (in t) flags its ray
     size_t max_export_bytes = (size_t)16 << 30; // budget of d_h8: bounds the rays per pass of skip_dead in a SPLIT arithmetic (NERF_MAX_EXPORT_BYTES);
                                                 // 16 GiB = 8 passes per 800x800 frame, 1.4 % slower than one pass of 128 GiB

@@ -59,5 +59,39 @@ hipError_t launch_composite(const CompositeArgs &a, hipStream_t st);
 hipError_t launch_box_downsample(const float *rays, float *out, int w, int h, int s, hipStream_t st);
 size_t resample_lds_bytes(int nc, int nf);
 size_t composite_lds_bytes(int n);
-// zero certification (experimental, nerf_api.cpp): list the samples whose bf16 pre-activation is not below -margin; zeroes `pre`
-hipError_t launch_uncertain_list(float *pre, int n, float margin, unsigned *list, unsigned *count, hipStream_t st);
+// ---- zero certification (nerf_render_opts.certify_zero; kernels and protocol: sampling_kernels.hip) ------------------------------------
+struct CertPlanArgs {
+    float *pre;          // in: the bf16 kernel's density pre-activations (n_rays x spr); out: 0, or a mark on uncertain samples behind j*
+    const float *t;      // n_rays x spr, ascending
+    int n_rays, spr;
+    float far_;
+    float margin;        // a sample is certified (density 0) iff pre < -margin
+    float depth_limit;   // predicted cut: the first sample with bf16 optical depth in front of it > depth_limit
+    unsigned audit_mask; // 2^k - 1: one certified sample in 2^k is audited
+    unsigned audit_salt;
+    unsigned *list;      // phase-1 list: sample index | (audit ? 1 << 31 : 0)
+    unsigned *count;     // += entries (also those beyond capacity)
+    unsigned capacity;
+    unsigned *aux;       // {sample index, bits of its bf16 pre-activation} of every audited certificate
+    unsigned *aux_count;
+    unsigned aux_capacity;
+    int *jstar;          // per ray: first sample behind the predicted cut (spr: none)
+    int rays_per_wave = 0; // set by launch_cert_plan
+};
+struct CertVerifyArgs {
+    const float *t;
+    float *sigma;        // the exact pass's density buffer (marks are cleared)
+    int n_rays, spr;
+    float far_;
+    const int *jstar;
+    unsigned *list;      // phase-2 list (no audit entries)
+    unsigned *count;
+    unsigned capacity;
+    unsigned *fallback_rays; // optional: += rays whose predicted cut was not confirmed
+};
+hipError_t launch_cert_plan(const CertPlanArgs &a, hipStream_t st);
+hipError_t launch_cert_verify(const CertVerifyArgs &a, hipStream_t st);
+// audit[0] += audited samples, audit[1] += violations, audit[2] = max(0x7f800000 - bits(min headroom)), audit[3] = max bits(|bf16 - exact|);
+// resets the audited entries of `sigma` to 0
+hipError_t launch_cert_audit(const unsigned *aux, const unsigned *aux_count, unsigned aux_capacity, float *sigma, unsigned *audit, int n_cus, hipStream_t st);
+size_t cert_plan_lds_bytes(int spr, int *rays_per_wave);

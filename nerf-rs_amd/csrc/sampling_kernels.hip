@@ -383,42 +383,215 @@ __global__ void k_box_downsample(const float *__restrict__ rays, float *__restri
     out[idx] = acc * (1.0f / (float)(s * s));
 }
 
-// ---- zero certification (experimental): which samples does the f32 kernel have to look at? ---------------------------------
-// `pre` holds the bf16 kernel's density PRE-activations.  A sample whose pre-activation is below -margin is a certain zero of the f32
-// network too (margin = several times the largest bf16-vs-f32 difference ever seen on such samples); every other sample -- positive,
-// near zero, NaN -- goes on the list.  The buffer is zeroed on the way: it becomes the f32 pass's sigma buffer, whose listed entries
-// the f32 kernel overwrites.  List order is arbitrary (one atomic per wave); results do not depend on it.
-// A wave handles kListSpan x 64 consecutive samples with ONE atomic (a counter shared by 2 M waves serialises: 7.8 ms per 123 M samples
-// with one atomic per 64 samples, profiles/r03cert_*).
-constexpr int kListSpan = 16;
-__global__ __launch_bounds__(256) void k_uncertain_list(float *__restrict__ pre, int n, float margin, unsigned *__restrict__ list, unsigned *__restrict__ count) {
-    const int lane = threadIdx.x & 63;
-    const long long wave0 = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * (kListSpan * 64);
-    unsigned long long mask[kListSpan];
-    unsigned total = 0;
-#pragma unroll
-    for (int k = 0; k < kListSpan; ++k) {
-        const long long i = wave0 + k * 64 + lane;
-        bool unc = false;
-        if (i < n) { unc = !(pre[i] < -margin); pre[i] = 0.0f; }
-        mask[k] = __ballot(unc);
-        total += (unsigned)__popcll(mask[k]);
-    }
-    if (total == 0) return; // wave-uniform
-    unsigned base = 0;
-    if (lane == 0) base = atomicAdd(count, total);
-    base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
-#pragma unroll
-    for (int k = 0; k < kListSpan; ++k) {
-        if ((mask[k] >> lane) & 1ull) list[base + (unsigned)__popcll(mask[k] & ((1ull << lane) - 1ull))] = (unsigned)(wave0 + k * 64 + lane);
-        base += (unsigned)__popcll(mask[k]);
-    }
+// ---- zero certification (nerf_render_opts.certify_zero): which samples does the exact kernel have to look at? ------------
+// `pre` holds the bf16 kernel's density PRE-activations of all samples of a pass (rays x spr).  Two exact facts of the reference make a
+// sample's exact evaluation unnecessary:
+//   (Z) its exact density is 0 (weight T * (1 - exp(-0 * delta)) = 0, src/lib.rs:271-272) -- CERTIFIED when the bf16 pre-activation is
+//       below -margin (margin = several times the bf16-vs-exact difference ever seen near 0; audited, see k_cert_audit);
+//   (C) it lies behind the ray's T < 1e-4 cut (src/lib.rs:276-279: every later weight is zero-filled whatever its density) -- PREDICTED
+//       from the bf16 densities, VERIFIED with the exact ones (k_cert_verify), so nothing rests on the prediction but the amount of work.
+// k_cert_plan walks every ray front to back (lanes = samples, optical depth by a wave prefix sum: a prediction needs no particular
+// summation order) and finds j* = the first sample whose bf16 transmittance exp(-depth) is below the prediction threshold (depth_limit =
+// -ln of it; kept well below the exact cut's 1e-4 so that the exact cut almost always falls inside [0, j*)).  Then
+//   * samples [0, j*): the UNCERTAIN ones (not certified: positive, near zero, NaN) go on the phase-1 list; of the certified ones a
+//     deterministic 1 / (audit_mask + 1) goes on the list too, with bit 31 set: the exact kernel evaluates them like any other listed
+//     sample but stores the raw pre-activation, which k_cert_audit compares with 0 and with the bf16 value (remembered in `aux`);
+//   * samples [j*, spr): uncertain ones are only MARKED (kCertMarker in the buffer); k_cert_verify either clears the marks (the exact
+//     transmittance over [0, j*) did fall below 1e-4: the ray is decided) or lists them for a second exact launch (rare);
+//   * the buffer is zeroed otherwise: it becomes the exact pass's density buffer, whose listed entries the exact kernel overwrites.
+// List order is arbitrary (one atomic per wave per kPlanRays rays, entries staged in LDS); results do not depend on it.  The list has a
+// CAPACITY: entries beyond it are counted, not stored -- the host sees count > capacity after the frame, grows the list and renders the
+// frame again (nerf_api.cpp).
+constexpr float kCertMarker = -1.0f;
+constexpr int kPlanRays = 8; // rays per wave between two flushes of its LDS staging area
+
+__device__ __forceinline__ bool cert_audit_pick(unsigned idx, unsigned salt, unsigned mask) {
+    return (((idx ^ salt) * 0x9E3779B1u) >> 7 & mask) == 0u; // a fixed pseudo-random 1 / (mask + 1) of the sample indices
 }
 
-hipError_t launch_uncertain_list(float *pre, int n, float margin, unsigned *list, unsigned *count, hipStream_t st) {
-    if (n <= 0) return hipSuccess;
-    const int per_block = 4 * kListSpan * 64;
-    hipLaunchKernelGGL(k_uncertain_list, dim3((n + per_block - 1) / per_block), dim3(256), 0, st, pre, n, margin, list, count);
+// dynamic LDS: 4 waves x (rays_per_wave x spr entries + kAuxStage {stage position, bf16 pre-activation} pairs)
+constexpr int kAuxStage = 96; // audited certificates a wave can stage between two flushes (expected: rays_per_wave x spr / 64); beyond: not audited
+__global__ __launch_bounds__(256) void k_cert_plan(CertPlanArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned lds_u[];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int spr = a.spr;
+    const size_t per_wave = (size_t)a.rays_per_wave * spr + 2 * kAuxStage;
+    unsigned *stage = lds_u + (size_t)wv * per_wave;
+    unsigned *aux_stage = stage + (size_t)a.rays_per_wave * spr;
+    const int ray0 = (blockIdx.x * 4 + wv) * a.rays_per_wave;
+    unsigned staged = 0, n_aux = 0; // wave-uniform
+    for (int rr = 0; rr < a.rays_per_wave; ++rr) {
+        const int ray = ray0 + rr;
+        if (ray >= a.n_rays) break; // wave-uniform
+        const size_t base = (size_t)ray * spr;
+        float carry = 0.0f; // optical depth in front of this group (bf16 densities)
+        int jstar = spr;
+        for (int g0 = 0; g0 < spr; g0 += 64) {
+            const int i = g0 + lane;
+            const bool in = i < spr;
+            float pre = 0.0f, od = 0.0f;
+            if (in) {
+                pre = a.pre[base + i];
+                const float t0 = a.t[base + i];
+                float delta = (i + 1 < spr ? a.t[base + i + 1] : a.far_) - t0;
+                if (delta < 0.0f) delta = 0.0f;
+                od = fmaxf(pre, 0.0f) * delta; // NaN pre-activation -> 0 here, and "uncertain" below
+            }
+            const bool unc = in && !(pre < -a.margin);
+            bool dead = jstar < spr; // a previous group already reached the predicted cut
+            if (!dead) {
+                float v = od;
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) { const float o = __shfl_up(v, off, 64); if (lane >= off) v += o; }
+                const float before = carry + (v - od); // depth in front of sample i
+                const unsigned long long dm = __ballot(in && before > a.depth_limit);
+                if (dm) jstar = g0 + (int)__builtin_ctzll(dm);
+                dead = i >= jstar;
+                carry += __shfl(v, 63, 64);
+            }
+            bool audit = in && !dead && !unc && cert_audit_pick((unsigned)(base + i), a.audit_salt, a.audit_mask);
+            const unsigned long long am = __ballot(audit);
+            const unsigned aux_at = n_aux + (unsigned)__popcll(am & ((1ull << lane) - 1ull));
+            audit = audit && aux_at < (unsigned)kAuxStage; // no room to remember its bf16 value: certified without audit, like its 63 siblings
+            const bool listed = (in && !dead && unc) || audit;
+            if (in) a.pre[base + i] = (dead && unc) ? kCertMarker : 0.0f;
+            const unsigned long long lm = __ballot(listed);
+            const unsigned at = staged + (unsigned)__popcll(lm & ((1ull << lane) - 1ull));
+            if (listed) stage[at] = (unsigned)(base + i) | (audit ? 0x80000000u : 0u);
+            if (audit) { aux_stage[2 * aux_at] = at; aux_stage[2 * aux_at + 1] = __float_as_uint(pre); }
+            staged += (unsigned)__popcll(lm);
+            n_aux = n_aux + (unsigned)__popcll(am);
+            n_aux = n_aux < (unsigned)kAuxStage ? n_aux : (unsigned)kAuxStage;
+        }
+        if (lane == 0) a.jstar[ray] = jstar;
+    }
+    if (staged == 0) return; // wave-uniform
+    wave_sync();
+    if (n_aux) { // remember {sample, bf16 pre-activation} of the audited certificates; one that does not fit is not audited (flag cleared)
+        unsigned at_aux = 0;
+        if (lane == 0) at_aux = atomicAdd(a.aux_count, n_aux);
+        at_aux = (unsigned)__builtin_amdgcn_readfirstlane((int)at_aux);
+        for (unsigned k = lane; k < n_aux; k += 64) {
+            const unsigned sp = aux_stage[2 * k];
+            if (at_aux + k < a.aux_capacity) { a.aux[2 * (size_t)(at_aux + k)] = stage[sp] & 0x7fffffffu; a.aux[2 * (size_t)(at_aux + k) + 1] = aux_stage[2 * k + 1]; }
+            else stage[sp] &= 0x7fffffffu;
+        }
+        wave_sync();
+    }
+    unsigned at = 0;
+    if (lane == 0) at = atomicAdd(a.count, staged);
+    at = (unsigned)__builtin_amdgcn_readfirstlane((int)at);
+    for (unsigned k = lane; k < staged; k += 64)
+        if (at + k < a.capacity) a.list[at + k] = stage[k];
+}
+
+// Exact transmittance over [0, j*) of every ray with a predicted cut (j* < spr): one wave per ray, alpha in parallel, the recurrence as
+// compute_weights has it (src/lib.rs:261-280; the same operations in the same order as weights_scan / k_composite above, on the same
+// buffer contents: exact densities of the listed samples, exact zeros of the certified ones).  If it falls below 1e-4 inside the prefix,
+// every sample from j* on has weight 0 whatever its density: the marks are cleared and the ray is done.  Otherwise (the bf16 prediction
+// was too optimistic) the marked samples are listed for the second exact launch.  LDS: 4 waves x spr floats.
+__global__ __launch_bounds__(256) void k_cert_verify(CertVerifyArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds_f[];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int ray = blockIdx.x * 4 + wv;
+    if (ray >= a.n_rays) return;
+    const int spr = a.spr, j = a.jstar[ray];
+    if (j >= spr) return; // no predicted cut: everything uncertain was on the first list
+    float *alpha = lds_f + (size_t)wv * spr;
+    const float *t = a.t + (size_t)ray * spr;
+    float *sg = a.sigma + (size_t)ray * spr;
+    for (int i = lane; i < j; i += 64) alpha[i] = sample_alpha(t, sg, i, spr, a.far_);
+    wave_sync();
+    float T = 1.0f;
+    bool cut = false;
+#pragma unroll 8
+    for (int i = 0; i < j; ++i) { // wave-uniform, branch-free form of the early break (see weights_scan)
+        const float al = alpha[i];
+        T = cut ? T : T * (1.0f - al);
+        cut = cut || T < 1e-4f;
+    }
+    unsigned n_more = 0;
+    for (int g0 = j; g0 < spr; g0 += 64) {
+        const int i = g0 + lane;
+        const bool marked = i < spr && sg[i] == kCertMarker;
+        if (marked) sg[i] = 0.0f;
+        if (cut) continue; // wave-uniform
+        const unsigned long long mm = __ballot(marked);
+        if (!mm) continue;
+        unsigned at = 0;
+        if (lane == 0) at = atomicAdd(a.count, (unsigned)__popcll(mm)); // rare path: one atomic per 64 samples is fine
+        at = (unsigned)__builtin_amdgcn_readfirstlane((int)at) + (unsigned)__popcll(mm & ((1ull << lane) - 1ull));
+        if (marked && at < a.capacity) a.list[at] = (unsigned)((size_t)ray * spr + i);
+        n_more += (unsigned)__popcll(mm);
+    }
+    if (n_more && lane == 0 && a.fallback_rays) atomicAdd(a.fallback_rays, 1u);
+}
+
+// The audit of (Z): `aux` holds {sample, bf16 pre-activation} of the certified samples that went on the list with bit 31 set -- the exact
+// kernel evaluated them all the same and left its RAW pre-activation in the density buffer.  A positive one is a VIOLATION (the
+// certificate was wrong; this sample now holds its true density, its unaudited siblings do not).  Otherwise -pre is how far the sample
+// stood from a positive density (HEADROOM = the minimum over the audited samples), and |pre_bf16 - pre_exact| is what the bf16 pass got
+// wrong on a sample it certified (MAX ERROR, at any depth below 0 -- samples right at the margin are rare in a network with large
+// pre-activations, its errors are not).  The host widens the margin and renders again when either uses up more than half the margin.
+// The buffer entry is reset to the exact kernel's value for such a sample: relu(pre) = 0.
+// audit[0] += audited, audit[1] += violations, audit[2] = max(0x7f800000 - bits(headroom)) (zero-initialised = +inf), audit[3] = max bits(|error|)
+__global__ __launch_bounds__(256) void k_cert_audit(const unsigned *__restrict__ aux, const unsigned *__restrict__ aux_count, unsigned aux_capacity,
+                                                    float *__restrict__ sigma, unsigned *__restrict__ audit) {
+    unsigned n = *aux_count;
+    n = n < aux_capacity ? n : aux_capacity;
+    const int lane = threadIdx.x & 63;
+    unsigned n_aud = 0, n_bad = 0, best = 0, worst = 0;
+    for (unsigned k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
+        const unsigned idx = aux[2 * (size_t)k];
+        const float pre_b = __uint_as_float(aux[2 * (size_t)k + 1]);
+        const float v = sigma[idx];
+        ++n_aud;
+        if (v <= 0.0f) {
+            const unsigned x = 0x7f800000u - __float_as_uint(-v); // -v >= 0 (or +0 for -0): bits ordered like the floats
+            best = x > best ? x : best;
+        } else ++n_bad; // positive or NaN
+        const float err = fabsf(pre_b - v);
+        if (err <= 3.0e38f) { const unsigned e = __float_as_uint(err); worst = e > worst ? e : worst; }
+        if (!(v > 0.0f)) sigma[idx] = 0.0f; // relu of a non-positive (or NaN: fmaxf(NaN, 0) = 0) pre-activation
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        n_aud += __shfl_xor(n_aud, off, 64); n_bad += __shfl_xor(n_bad, off, 64);
+        unsigned o = __shfl_xor(best, off, 64); best = o > best ? o : best;
+        o = __shfl_xor(worst, off, 64); worst = o > worst ? o : worst;
+    }
+    if (lane == 0 && n_aud) { atomicAdd(audit, n_aud); if (n_bad) atomicAdd(audit + 1, n_bad); atomicMax(audit + 2, best); atomicMax(audit + 3, worst); }
+}
+
+size_t cert_plan_lds_bytes(int spr, int *rays_per_wave) {
+    int r = (int)((size_t)(96 * 1024) / ((size_t)4 * spr * sizeof(unsigned)));
+    r = r > kPlanRays ? kPlanRays : r;
+    if (r < 1) r = 1;
+    if (rays_per_wave) *rays_per_wave = r;
+    return (size_t)4 * ((size_t)r * spr + 2 * kAuxStage) * sizeof(unsigned);
+}
+
+hipError_t launch_cert_plan(const CertPlanArgs &a, hipStream_t st) {
+    if (a.n_rays <= 0 || a.spr <= 0) return hipSuccess;
+    CertPlanArgs b = a;
+    const size_t lds = cert_plan_lds_bytes(a.spr, &b.rays_per_wave);
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    const int rays_per_block = 4 * b.rays_per_wave;
+    hipLaunchKernelGGL(k_cert_plan, dim3((a.n_rays + rays_per_block - 1) / rays_per_block), dim3(256), lds, st, b);
+    return hipGetLastError();
+}
+
+hipError_t launch_cert_verify(const CertVerifyArgs &a, hipStream_t st) {
+    if (a.n_rays <= 0 || a.spr <= 0) return hipSuccess;
+    const size_t lds = (size_t)4 * a.spr * sizeof(float);
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_cert_verify, dim3((a.n_rays + 3) / 4), dim3(256), lds, st, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_cert_audit(const unsigned *aux, const unsigned *aux_count, unsigned aux_capacity, float *sigma, unsigned *audit, int n_cus, hipStream_t st) {
+    if (aux_capacity == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_cert_audit, dim3(n_cus > 0 ? 2 * n_cus : 512), dim3(256), 0, st, aux, aux_count, aux_capacity, sigma, audit);
     return hipGetLastError();
 }
 
@@ -444,6 +617,8 @@ size_t composite_lds_bytes(int) { return sizeof(float) * 64 * (2 * kCompTS + kCo
 
 hipError_t sampling_init(void) {
     hipError_t e = hipFuncSetAttribute((const void *)k_resample, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_cert_plan, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_cert_verify, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     return e;
 }
 

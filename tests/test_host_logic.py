@@ -27,7 +27,7 @@ def test_abi_exports_every_declared_symbol(native):
         assert hasattr(L, name), f"{name} declared in the header but not exported"
         assert name in _lib.PROTOTYPES, f"{name} has no ctypes prototype"
     assert set(_lib.PROTOTYPES) == declared
-    assert native.load_library().nerf_abi_version() == 4
+    assert native.load_library().nerf_abi_version() == 5
     assert native.load_library().nerf_build_variant() == b""      # the product build; variants carry a tag and are refused by the loader
 
 
@@ -424,7 +424,8 @@ def test_rust_sys_crate_matches_the_header_types():
     from nerf_rs_amd import _lib
     htext = open(HEADER).read()
     rs = re.sub(r"//.*", "", open(os.path.join(ROOT, "bindings", "rust", "nerf-mi355x-sys", "src", "lib.rs")).read())
-    ctypes_names = {C.c_int32: "i32", C.c_uint32: "u32", C.c_uint64: "u64", C.c_float: "f32", C.c_double: "f64", C.c_float * 3: "[f32; 3]"}
+    ctypes_names = {C.c_int32: "i32", C.c_uint32: "u32", C.c_uint64: "u64", C.c_float: "f32", C.c_double: "f64", C.c_float * 3: "[f32; 3]",
+                    C.c_float * 2: "[f32; 2]"}
     for struct, mirror in (("nerf_camera", _lib.CCamera), ("nerf_render_opts", _lib.COpts), ("nerf_stats", _lib.CStats)):
         want = _c_struct_fields(htext, struct)
         body = rs[rs.index(f"pub struct {struct} {{"):]
@@ -453,7 +454,7 @@ def test_struct_sizes_match_the_library(native):
     L = native.load_library()
     a, b, c = C.c_size_t(), C.c_size_t(), C.c_size_t()
     L.nerf_abi_struct_sizes(C.byref(a), C.byref(b), C.byref(c))
-    assert (a.value, b.value, c.value) == (C.sizeof(_lib.CCamera), C.sizeof(_lib.COpts), C.sizeof(_lib.CStats)) == (60, 64, 112)
+    assert (a.value, b.value, c.value) == (C.sizeof(_lib.CCamera), C.sizeof(_lib.COpts), C.sizeof(_lib.CStats)) == (60, 64, 160)
 
 
 def test_loader_rejects_a_directory_named_like_a_tensor(native, tmp_path):
@@ -509,3 +510,17 @@ def test_make_variant_tags_every_compile_line():
     bare = subprocess.run(["make", "-n", "-C", csrc, "variant", "NAME=y"], capture_output=True, text=True, check=True).stdout
     assert all("-DNERF_BUILD_VARIANT='\"y: \"'" in l for l in bare.splitlines() if " -c " in l)
     assert subprocess.run(["make", "-C", csrc, "variant"], capture_output=True, text=True).returncode != 0  # NAME is required
+
+
+def test_abi_version_is_stated_consistently(native):
+    """One number, five places: nerf_abi_version(), the header's history comment, the Rust -sys crate (doc line and check_layouts),
+    DESIGN.md's boundary row and INTEGRATION.md (round 3 left three of them behind)."""
+    v = native.load_library().nerf_abi_version()
+    h = open(HEADER).read()
+    assert f"ABI version (currently {v})" in h and re.search(rf"\b{v}: nerf_", h)
+    assert not re.search(rf"\b{v + 1}: nerf_", h)
+    rs = open(os.path.join(ROOT, "bindings", "rust", "nerf-mi355x-sys", "src", "lib.rs")).read()
+    assert f"(ABI version {v})" in rs.splitlines()[0] and f"nerf_abi_version() }} == {v} " in rs and f"expects ABI {v} with" in rs
+    assert f"C ABI (ABI version {v})" in open(os.path.join(ROOT, "DESIGN.md")).read()
+    assert f"`nerf_abi_version` ({v})" in open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    assert f"nerf_abi_version() == {v}" in open(os.path.join(ROOT, "__graft_entry__.py")).read()

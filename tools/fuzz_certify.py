@@ -21,7 +21,8 @@ S = json.load(open(os.path.join(ROOT, "lego_rust", "tf_reference_samples.json"))
 
 def fuzz(r, budget, rng_seed):
     rng = np.random.default_rng(rng_seed)
-    tot = dict(cases=0, rays=0, mismatching=0, f32_samples_nominal=0, f32_samples_evaluated=0)
+    tot = dict(cases=0, rays=0, mismatching=0, f32_samples_nominal=0, f32_samples_evaluated=0, retries=0, violations=0, audited=0, fallback_rays=0,
+               worst_error_over_margin=[0.0, 0.0], least_headroom_over_margin=[9.9, 9.9], margins=None)
     t_end = time.time() + budget
     while time.time() < t_end:
         W = int(rng.choice([64, 128, 200, 400, 800]))
@@ -36,6 +37,11 @@ def fuzz(r, budget, rng_seed):
         tot["cases"] += 1; tot["rays"] += st.n_rays
         tot["f32_samples_nominal"] += st.n_coarse_points + st.n_fine_points
         tot["f32_samples_evaluated"] += st.n_exec_coarse_trunk + st.n_exec_fine_trunk
+        tot["retries"] += st.n_certify_retries; tot["violations"] += st.n_certify_violations; tot["audited"] += st.n_certify_audited
+        tot["fallback_rays"] += st.n_certify_fallback_rays; tot["margins"] = list(st.certify_margin)
+        for w in range(2):
+            tot["worst_error_over_margin"][w] = max(tot["worst_error_over_margin"][w], st.certify_max_error[w] / st.certify_margin[w])
+            tot["least_headroom_over_margin"][w] = min(tot["least_headroom_over_margin"][w], st.certify_headroom[w] / st.certify_margin[w])
         if not np.array_equal(img, ref):
             tot["mismatching"] += 1
             d = np.abs(img - ref)
@@ -43,9 +49,28 @@ def fuzz(r, budget, rng_seed):
     return tot
 
 
+def scaled_scene(root, scale):
+    """lego with dense7 (kernel and bias) scaled: every density pre-activation, and the bf16 pass's error on it, grows by `scale`."""
+    import shutil
+    for which in ("coarse", "fine"):
+        shutil.copytree(os.path.join(ROOT, "lego_rust", which), os.path.join(root, which))
+        for t in ("dense7_kernel", "dense7_bias"):
+            f = os.path.join(root, which, t + ".bin")
+            (np.fromfile(f, "<f4") * np.float32(scale)).astype("<f4").tofile(f)
+    return root
+
+
 if __name__ == "__main__":
-    with N.Renderer(0) as r:
-        r.load_scene(os.path.join(ROOT, "lego_rust"))
-        res = fuzz(r, float(sys.argv[1]) if len(sys.argv) > 1 else 60.0, int(sys.argv[2]) if len(sys.argv) > 2 else 1)
-    print(json.dumps(res))
-    sys.exit(1 if res["mismatching"] else 0)
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    scales = [float(x) for x in sys.argv[3].split(",")] if len(sys.argv) > 3 else [1.0]   # e.g. 1,3,10,40: hotter networks than lego
+    bad = 0
+    for k, scale in enumerate(scales):
+        import tempfile
+        with tempfile.TemporaryDirectory() as tmp, N.Renderer(0) as r:
+            r.load_scene(os.path.join(ROOT, "lego_rust") if scale == 1.0 else scaled_scene(os.path.join(tmp, "s"), scale))
+            res = fuzz(r, budget / len(scales), seed + k)
+        res["pre_activation_scale"] = scale
+        print(json.dumps(res), flush=True)
+        bad += res["mismatching"]
+    sys.exit(1 if bad else 0)

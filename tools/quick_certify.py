@@ -26,7 +26,8 @@ with N.Renderer(0) as r:
         ok &= same
         print(f"{W}x{W} crop {crop} {nc}+{nf} coarse_only {co} ssaa {ssaa}: identical={same} (max diff {np.abs(a - b).max():.2e}); plain {best0.ms_total:.1f} ms -> certified {best.ms_total:.1f} ms "
               f"(coarse {best.ms_coarse_mlp:.1f} fine {best.ms_fine_mlp:.1f} other {best.ms_other:.1f}); f32 kernel evaluates coarse {best.n_exec_coarse_trunk / max(best.n_coarse_points, 1):.3f} "
-              f"fine {best.n_exec_fine_trunk / max(best.n_fine_points, 1):.3f} of the samples", flush=True)
+              f"fine {best.n_exec_fine_trunk / max(best.n_fine_points, 1):.3f} of the samples; audited {best.n_certify_audited} violations {best.n_certify_violations} "
+              f"headroom {best.certify_headroom} margins {best.certify_margin} fallback rays {best.n_certify_fallback_rays} retries {best.n_certify_retries}", flush=True)
     cam = N.camera_from_samples(S, 800, 800, 64)
     for dt in ("f16x2", "bf16x3"):
         a = N.render_image(r.coarse, r.fine, cam, 128, seed=1, dtype=dt)
@@ -36,6 +37,6 @@ with N.Renderer(0) as r:
             if best is None or st.ms_total < best.ms_total: best = st
         same = np.array_equal(a, b); ok &= same
         print(f"{dt} C3 frame: identical={same}; certified {best.ms_total:.1f} ms (coarse {best.ms_coarse_mlp:.1f} fine {best.ms_fine_mlp:.1f} other {best.ms_other:.1f}); "
-              f"nonfinite {best.n_nonfinite_points}", flush=True)
+              f"nonfinite {best.n_nonfinite_points}; fine list {best.n_exec_fine_trunk / max(best.n_fine_points, 1):.3f} headroom {best.certify_headroom} fallback rays {best.n_certify_fallback_rays}", flush=True)
 print("ALL IDENTICAL" if ok else "MISMATCH")
 sys.exit(0 if ok else 1)
