@@ -25,11 +25,11 @@ PEAK_FP32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, "Peak F
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # same table, "Peak BF16/FP16 MFMA ~2.5 PF dense"
 
 
-PROFILE_ROUND = "r03"  # the round whose committed rocprofv3 summaries (profiles/r03*) describe the kernels this bench.py runs
+PROFILE_ROUND = "r04"  # the round whose committed rocprofv3 summaries (profiles/r03*) describe the kernels this bench.py runs
 
 
 def pmc_traffic_bytes(kernel_prefix="void nerf_mlp_kernel<true"):
-    """HBM bytes per launch of the dominant kernel from THIS round's committed rocprofv3 PMC passes (profiles/r03*_pmc_summary.csv:
+    """HBM bytes per launch of the dominant kernel from THIS round's committed rocprofv3 PMC passes (profiles/r04*_pmc_summary.csv:
     separate FETCH_SIZE / WRITE_SIZE runs; FETCH_SIZE doubled per the gfx950 note in MI355X_MICROARCH.md).  PMC counters cannot be
     collected from inside the run, so this is the profile of the same command, not a per-run measurement; there is no fallback to an
     earlier round's profile: without a current summary for the selected kernel `traffic` is null and the line says why.
@@ -288,7 +288,7 @@ def main():
         r.kernel_time_query(reset=True)
     cert_stats = None
     if args.certify_zero and world == 1:  # one extra untimed frame with stats: the list lengths are deterministic per frame
-        cert_stats = N.render_image(r.coarse, r.fine, cam, args.fine, seed=args.seed, ssaa=args.ssaa, certify_zero=True,
+        cert_stats = N.render_image(r.coarse, r.fine, cam, args.fine, seed=args.seed, ssaa=args.ssaa, dtype=args.dtype, certify_zero=True,
                                     device_out=frame.data_ptr(), stream=stream, return_stats=True)
         r.kernel_time_query(reset=True)
     # Reported separately, never part of `value`: the same frame with exact empty-tile skipping.
@@ -382,9 +382,17 @@ def main():
                       "f32_evaluated_fraction_coarse": st.n_exec_coarse_trunk / max(st.n_coarse_points, 1),
                       "f32_evaluated_fraction_fine": st.n_exec_fine_trunk / max(st.n_fine_points, 1),
                       "device_ms": {"total": st.ms_total, "coarse_bf16_pass_plus_f32_list": st.ms_coarse_mlp, "fine_bf16_pass_plus_f32_list": st.ms_fine_mlp, "other": st.ms_other},
-                      "note": "opt-in certify_zero: a bf16 pass over all samples certifies those whose density pre-activation is below -1 (coarse) / -2 (fine) "
-                              "as zeros of the f32 network too; the f32 MFMA kernel evaluates only the others from a device-side list; certified samples "
-                              "have weight 0, so the frame is the headline frame bit for bit (fuzzed: tools/fuzz_certify.py)"}
+                      "audit": {"certified_samples_evaluated_all_the_same": st.n_certify_audited, "violations": st.n_certify_violations,
+                                "margins_coarse_fine": list(st.certify_margin), "least_headroom_coarse_fine": list(st.certify_headroom),
+                                "largest_bf16_error_on_an_audited_certificate_coarse_fine": list(st.certify_max_error),
+                                "frame_rendered_again": st.n_certify_retries},
+                      "rays_whose_predicted_cut_was_not_confirmed": st.n_certify_fallback_rays,
+                      "note": "opt-in certify_zero (DESIGN 4.9): a bf16 pass over all samples certifies those whose density pre-activation is below minus the "
+                              "network's margin as zeros of the f32 network too and predicts each ray's T < 1e-4 cut; the f32 MFMA kernel evaluates only the "
+                              "other samples in front of the predicted cut (a device-side list), the exact transmittance confirms the cut; certified samples "
+                              "and samples behind the cut have weight 0, so the frame is the headline frame bit for bit; one certified sample in 64 is "
+                              "evaluated all the same (the audit: a wrong or nearly wrong certificate widens the margin and the frame is rendered again); "
+                              "fuzzed: tools/fuzz_certify.py"}
         r.kernel_time_query(reset=True)
     extra_split = {}
     if world == 1 and args.dtype == "f32" and not args.skip_empty and not args.skip_dead and not args.certify_zero and not args.no_extra:
@@ -443,6 +451,9 @@ def main():
                 "rays_per_s": n_r / (ms * 1e-3), "ms_per_step": ms, f"image_bit_identical_to_the_{arith}_frame": identical,
                 "evaluated_fraction_coarse_f32": st.n_exec_coarse_trunk / max(st.n_coarse_points, 1),
                 f"evaluated_fraction_fine_{arith}": st.n_exec_fine_trunk / max(st.n_fine_points, 1),
+                "audit": {"certified_samples_evaluated_all_the_same": st.n_certify_audited, "violations": st.n_certify_violations,
+                          "least_headroom_coarse_fine": list(st.certify_headroom), "margins_coarse_fine": list(st.certify_margin),
+                          "frame_rendered_again": st.n_certify_retries},
                 "device_ms": {"total": st.ms_total, "coarse_bf16_pass_plus_f32_list": st.ms_coarse_mlp, f"fine_bf16_pass_plus_{arith}_list": st.ms_fine_mlp, "other": st.ms_other}}
             # ... and with the sampling pass in the split arithmetic too, ill-conditioned rays redone in f32
             def hyb_step(stats=False):

@@ -48,6 +48,9 @@ pub struct nerf_render_opts {
     pub skip_dead: i32,
     pub hybrid_sampling: i32,
     pub certify_zero: i32,
+    pub band_index: i32,
+    pub band_count: i32,
+    pub band_stripe_rows: i32,
 }
 
 #[repr(C)]
@@ -129,6 +132,7 @@ extern "C" {
                                    gather: c_int, rgb_out: *mut f32, per_ctx: *mut nerf_stats) -> c_int;
     pub fn nerf_create_multi(device_ids: *const c_int, n: c_int, out: *mut *mut nerf_ctx) -> c_int;
     pub fn nerf_multi_release();
+    pub fn nerf_band_rows(window_rows: c_int, band_index: c_int, band_count: c_int, band_stripe_rows: c_int) -> c_int;
     pub fn nerf_kernel_time_query(ctx: *mut nerf_ctx, ms: *mut f64, points: *mut u64, n_launches: *mut u32, reset: c_int) -> c_int;
     pub fn nerf_camera_from_json(json_path: *const c_char, width: c_int, height: c_int, out: *mut nerf_camera) -> c_int;
     pub fn nerf_camera_from_pose(c2w: *const f32, ref_h: f32, ref_w: f32, focal: f32, near: f32, far: f32, width: c_int,

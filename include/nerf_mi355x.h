@@ -119,6 +119,15 @@ typedef struct {
                            * unobserved is a wrong certificate that is so rare that a 1-in-64 audit of ~1e8 certified samples per frame never
                            * meets one or its precursors.  Because of the audit a certify_zero render synchronises the stream before it returns
                            * (also nerf_render_image_device with stats == NULL).  nerf_stats.n_exec_* = samples the exact kernel evaluated. */
+    /* ext (ABI 5): render only ONE BAND of the output window's rows (the whole window when band_count <= 1) -- what one GPU of several
+     * renders (nerf_render_image_multi and nerf-rs_amd/distributed.py set these; reference counterpart: the rayon fan-out over blocks,
+     * src/lib.rs:533-550, which balances by work stealing).  band_stripe_rows = 0: band band_index of band_count CONTIGUOUS bands (the
+     * first rows % count bands one row longer) -- balanced when every ray costs the same.  band_stripe_rows = S > 0: the window's rows
+     * are dealt out in stripes of S rows round-robin, this call renders the stripes band_index, band_index + band_count, ... -- balanced
+     * also when rays differ in cost (skip_dead, certify_zero: the lego background, 75 % of the rays, is nearly free and sits in the top
+     * rows).  rgb_out holds the band's rows PACKED, in frame order: nerf_band_rows(window rows, ...) x width x 3.  Every pixel is the same
+     * bits as in a whole-window render (per-pixel counter RNG). */
+    int32_t band_index, band_count, band_stripe_rows;
 } nerf_render_opts;
 
 /* Device-side timing of the last render (HIP events on the render stream). */
@@ -215,9 +224,10 @@ int nerf_render_image_device(nerf_ctx *ctx, const nerf_camera *cam, const nerf_r
                              void *stream, nerf_stats *stats);
 /* ---- S3 over several GPUs of one node (reference: the rayon fan-out over blocks + scatter, src/lib.rs:533-557) ------
  * ctxs[i] is one context per device (nerf_create / nerf_create_multi), each with both networks loaded (weights are
- * replicated).  Context i renders a contiguous band of the output rows -- band i of n: first row i*(h/n) + min(i, h%n),
- * h/n + (i < h%n) rows -- on its own host thread and stream; a band is bit-identical to the same rows of a single-context
- * frame (per-pixel counter RNG).  `gather` selects how the bands meet in rgb_out (host, same layout as nerf_render_image):
+ * replicated).  Context i renders band i of n of the output rows (nerf_render_opts.band_*, set here: the caller's values are
+ * ignored) on its own host thread and stream: CONTIGUOUS bands -- first row i*(h/n) + min(i, h%n), h/n + (i < h%n) rows -- when every
+ * ray costs the same, single rows dealt out round-robin (band_stripe_rows = 1) when opts->skip_dead, skip_empty or certify_zero make
+ * the cost follow the scene; a band is bit-identical to the same rows of a single-context frame (per-pixel counter RNG).  `gather` selects how the bands meet in rgb_out (host, same layout as nerf_render_image):
  *   NERF_GATHER_HOST  each band is copied device -> host into its rows directly (no GPU-to-GPU traffic);
  *   NERF_GATHER_PEER  bands are copied GPU -> GPU over xGMI (hipMemcpyPeerAsync) into a frame on ctxs[0]'s device, then one D2H;
  *   NERF_GATHER_RCCL  ONE ncclAllGather of the bands (RCCL over xGMI; librccl is dlopen'ed on first use): the whole frame
@@ -235,6 +245,10 @@ int nerf_render_image_multi(nerf_ctx *const *ctxs, int n, const nerf_camera *cam
 int nerf_create_multi(const int *device_ids, int n, nerf_ctx **out /* n entries */);
 /* Frees the cached RCCL communicators of NERF_GATHER_RCCL (optional; call after the contexts are idle). */
 void nerf_multi_release(void);
+
+/* Rows of band band_index when window_rows rows are split over band_count bands (nerf_render_opts.band_*); host-only.  Negative
+ * (NERF_ERR_INVALID) on bad arguments. */
+int nerf_band_rows(int window_rows, int band_index, int band_count, int band_stripe_rows);
 
 /* Accumulated device time of the dominant (fine- or coarse-only-MLP) kernel since the last reset: blocks until the
  * recorded events have completed.  Used by bench.py for the roofline line. */
@@ -291,7 +305,8 @@ int nerf_stage_integrate(nerf_ctx *ctx, size_t n_rays, int n, float far_, const 
 const char *nerf_build_variant(void);
 /* ABI version (currently 5): bumped on any signature or struct change (2: multi-GPU entry points, skip_dead, n_exec_* statistics; 3: nerf_stats.
  * n_nonfinite_points, nerf_check_network_blob, nerf_stage_hybrid_flags, nerf_build_variant; 4: nerf_render_opts.certify_zero; 5: nerf_stats.
- * n_certify_* / certify_margin / certify_headroom / certify_max_error, renders fail on n_nonfinite_points != 0). */
+ * n_certify_* / certify_margin / certify_headroom / certify_max_error, renders fail on n_nonfinite_points != 0,
+ * nerf_render_opts.band_*, nerf_band_rows). */
 int nerf_abi_version(void);
 /* sizeof(nerf_camera), sizeof(nerf_render_opts), sizeof(nerf_stats) as this library was built: lets a binding written in
  * another language (the Rust `-sys` crate, ctypes) check its struct mirrors at start-up. */

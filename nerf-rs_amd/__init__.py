@@ -5,9 +5,9 @@ sitting on top of the C ABI of libnerf_mi355x.so (include/nerf_mi355x.h).  PyTor
 (device buffers, streams, torch.distributed over RCCL for the framebuffer gather).
 """
 from ._lib import NerfError, build_native, lib_path, load_library  # noqa: F401
-from .api import (Camera, Network, RenderOpts, Renderer, Stats, camera_from_pose, camera_from_samples,  # noqa: F401
+from .api import (Camera, Network, RenderOpts, Renderer, Stats, band_row_indices, band_rows, camera_from_pose, camera_from_samples,  # noqa: F401
                   load_network_blob, load_network_from_dir, pack_network_dir, quantize_rgb8, quantize_rgba8, render_image, render_image_multi, save_ppm)
-from .distributed import band_of_rank, render_image_distributed  # noqa: F401
+from .distributed import band_of_rank, partition_for, render_image_distributed  # noqa: F401
 
 FLOP_PER_POINT_FULL = 1_186_816   # SURVEY.md section 8(d)
 FLOP_PER_POINT_SIGMA = 982_528

@@ -28,7 +28,8 @@ class CCamera(C.Structure):
 class COpts(C.Structure):
     _fields_ = [("n_coarse", C.c_int32), ("n_fine", C.c_int32), ("coarse_only", C.c_int32),
                 ("crop_x0", C.c_int32), ("crop_y0", C.c_int32), ("crop_w", C.c_int32), ("crop_h", C.c_int32),
-                ("ssaa", C.c_int32), ("seed", C.c_uint64), ("mlp_dtype", C.c_int32), ("skip_empty", C.c_int32), ("skip_dead", C.c_int32), ("hybrid_sampling", C.c_int32), ("certify_zero", C.c_int32)]
+                ("ssaa", C.c_int32), ("seed", C.c_uint64), ("mlp_dtype", C.c_int32), ("skip_empty", C.c_int32), ("skip_dead", C.c_int32), ("hybrid_sampling", C.c_int32), ("certify_zero", C.c_int32),
+                ("band_index", C.c_int32), ("band_count", C.c_int32), ("band_stripe_rows", C.c_int32)]
 
 
 class CStats(C.Structure):
@@ -75,6 +76,7 @@ PROTOTYPES = {
                                           C.POINTER(CStats)]),
     "nerf_create_multi": (C.c_int, [C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p)]),
     "nerf_multi_release": (None, []),
+    "nerf_band_rows": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "nerf_kernel_time_query": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64),
                                          C.POINTER(C.c_uint32), C.c_int]),
     "nerf_debug_shader_clock_mhz": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),

@@ -218,7 +218,8 @@ def camera_from_pose(c2w, hwf, near, far, width, height, coarse_samples_per_ray=
 
 class RenderOpts:
     def __init__(self, n_coarse=64, n_fine=128, coarse_only=False, crop=None, ssaa=1, seed=0, dtype="f32", skip_empty=False,
-                 skip_dead=False, hybrid_sampling=False, certify_zero=False):
+                 skip_dead=False, hybrid_sampling=False, certify_zero=False, band=None):
+        self.band = tuple(int(v) for v in band) if band else None   # (index, count, stripe_rows): nerf_render_opts.band_*
         self.hybrid_sampling = bool(hybrid_sampling)
         self.certify_zero = bool(certify_zero)
         self.n_coarse, self.n_fine, self.coarse_only, self.crop, self.ssaa, self.seed = \
@@ -236,16 +237,44 @@ class RenderOpts:
         o.skip_dead = int(self.skip_dead)
         o.hybrid_sampling = int(self.hybrid_sampling)
         o.certify_zero = int(self.certify_zero)
+        if self.band:
+            o.band_index, o.band_count, o.band_stripe_rows = self.band
         return o
 
     def out_shape(self, cam):
-        return (self.crop[3], self.crop[2], 3) if self.crop else (cam.ny, cam.nx, 3)
+        h, w = (self.crop[3], self.crop[2]) if self.crop else (cam.ny, cam.nx)
+        if self.band and self.band[1] > 1:
+            h = band_rows(h, *self.band)
+        return (h, w, 3)
+
+
+def band_rows(window_rows, index, count, stripe_rows=0):
+    """Rows of band `index` of `count` (nerf_band_rows): stripe_rows = 0 contiguous bands, > 0 stripes of that many rows round-robin."""
+    n = _lib.load_library().nerf_band_rows(int(window_rows), int(index), int(count), int(stripe_rows))
+    if n < 0:
+        raise NerfError(n, "nerf_band_rows: bad argument")
+    return n
+
+
+def band_row_indices(window_rows, index, count, stripe_rows=0):
+    """The window rows band `index` holds, in the order it holds them (the layout nerf_render_opts.band_* documents)."""
+    h, n = int(window_rows), max(int(count), 1)
+    if n == 1:
+        return np.arange(h)
+    if stripe_rows <= 0:
+        base, rem = divmod(h, n)
+        y0 = index * base + min(index, rem)
+        return np.arange(y0, y0 + base + (1 if index < rem else 0))
+    rows = np.arange(h)
+    return rows[(rows // stripe_rows) % n == index]
 
 
 def render_image(coarse, fine, camera, fine_samples_per_ray=128, *, seed=0, coarse_only=False, crop=None, ssaa=1,
-                 dtype="f32", skip_empty=False, skip_dead=False, hybrid_sampling=False, certify_zero=False, return_stats=False, device_out=None,
-                 stream=0):
+                 dtype="f32", skip_empty=False, skip_dead=False, hybrid_sampling=False, certify_zero=False, band=None, return_stats=False,
+                 device_out=None, stream=0):
     """render_image (src/lib.rs:474-565) -> (h, w, 3) float32 linear RGB.
+
+    band = (index, count, stripe_rows): only that band of the window's rows, packed (nerf_render_opts.band_*).
 
     coarse/fine: Network objects of one Renderer; camera.samples_per_ray is the coarse sample count.
     device_out: optional raw device pointer (int) to receive the image instead of a host array (asynchronous on
@@ -253,7 +282,7 @@ def render_image(coarse, fine, camera, fine_samples_per_ray=128, *, seed=0, coar
     R = coarse.renderer
     if fine is not None and fine.renderer is not R:
         raise NerfError(-1, "coarse and fine networks must live in the same Renderer")
-    opts = RenderOpts(camera.samples_per_ray, fine_samples_per_ray, coarse_only, crop, ssaa, seed, dtype, skip_empty, skip_dead, hybrid_sampling, certify_zero)
+    opts = RenderOpts(camera.samples_per_ray, fine_samples_per_ray, coarse_only, crop, ssaa, seed, dtype, skip_empty, skip_dead, hybrid_sampling, certify_zero, band)
     o = opts.to_c()
     st = CStats()
     if device_out is not None:

@@ -374,6 +374,17 @@ int render_once(nerf_ctx *c, const nerf_camera *cam, const nerf_render_opts *o, 
     if (o->crop_w > 0 || o->crop_h > 0) { x0 = o->crop_x0; y0 = o->crop_y0; cw = o->crop_w; ch = o->crop_h; }
     if (cw <= 0 || ch <= 0 || x0 < 0 || y0 < 0 || x0 + cw > cam->nx || y0 + ch > cam->ny)
         return fail(c, NERF_ERR_INVALID, "crop window outside the frame");
+    // one band of the window's rows (multi-GPU): contiguous bands are just a shorter window; striped bands keep the window and map
+    // band-local rows to window rows in the ray generator (sampling_kernels.hip ray_row)
+    int stripe = 0;
+    if (o->band_count > 1) {
+        if (o->band_index < 0 || o->band_index >= o->band_count || o->band_stripe_rows < 0) return fail(c, NERF_ERR_INVALID, "band_index / band_count / band_stripe_rows out of range");
+        const int rows = band_rows(ch, o->band_index, o->band_count, o->band_stripe_rows);
+        if (rows <= 0) return fail(c, NERF_ERR_INVALID, "this band has no rows (more bands than rows)");
+        if (o->band_stripe_rows == 0) y0 += band_first_row(ch, o->band_index, o->band_count);
+        else stripe = o->band_stripe_rows;
+        ch = rows;
+    } else if (o->band_count < 0) return fail(c, NERF_ERR_INVALID, "band_count must be >= 0");
     const int nc = o->n_coarse;
     // sample_importance returns nothing for count == 0 or < 3 coarse samples (src/lib.rs:295-297): the fine net
     // then runs on the coarse samples only
@@ -482,12 +493,13 @@ int render_once(nerf_ctx *c, const nerf_camera *cam, const nerf_render_opts *o, 
     if (watch_range) HIP_TRY(c, hipMemsetAsync(c->d_nonfinite, 0, sizeof(unsigned int), st));
     const bool timing = true;
     RayGenArgs g = make_raygen(*cam, s);
+    if (stripe > 0) { g.stripe = stripe * s; g.stripe_n = o->band_count; g.stripe_i = o->band_index; g.stripe_y0 = RY0; }
     const DevNet &NC = c->net[NERF_NET_COARSE], &NF = c->net[NERF_NET_FINE];
     uint32_t passes = 0;
     for (int row = 0; row < RH; row += (int)rows_per_pass, ++passes) {
         const int rows = std::min<int>((int)rows_per_pass, RH - row);
         const int n_rays = rows * RW;
-        g.n_rays = n_rays; g.rx0 = RX0; g.ry0 = RY0 + row; g.rw = RW;
+        g.n_rays = n_rays; g.rx0 = RX0; g.ry0 = (stripe > 0 ? 0 : RY0) + row; g.rw = RW;
         {
             Timed t(c, st, 2, 0, timing);
             HIP_TRY(c, launch_ray_dirs(g, c->d_dirs, st));
@@ -1065,8 +1077,14 @@ int nerf_render_image(nerf_ctx *c, const nerf_camera *cam, const nerf_render_opt
     if (!opts) return fail(c, NERF_ERR_INVALID, "opts is NULL");
     DeviceGuard dg(c->device);
     const bool crop = opts->crop_w > 0 || opts->crop_h > 0;
-    const long long w = crop ? opts->crop_w : cam->nx, h = crop ? opts->crop_h : cam->ny;
+    const long long w = crop ? opts->crop_w : cam->nx;
+    long long h = crop ? opts->crop_h : cam->ny;
     if (w <= 0 || h <= 0) return fail(c, NERF_ERR_INVALID, "crop window outside the frame");
+    if (opts->band_count > 1) {
+        if (opts->band_index < 0 || opts->band_index >= opts->band_count || opts->band_stripe_rows < 0) return fail(c, NERF_ERR_INVALID, "band_index / band_count / band_stripe_rows out of range");
+        h = band_rows((int)h, opts->band_index, opts->band_count, opts->band_stripe_rows);
+        if (h <= 0) return fail(c, NERF_ERR_INVALID, "this band has no rows (more bands than rows)");
+    }
     const size_t bytes = (size_t)w * h * 3 * sizeof(float);
     if ((rc = ensure_bytes(c, (void **)&c->d_out, &c->out_floats, bytes))) return rc;
     nerf_stats local; // a synchronous render always reads its counters: a frame computed outside a split arithmetic's range is an error
@@ -1075,6 +1093,12 @@ int nerf_render_image(nerf_ctx *c, const nerf_camera *cam, const nerf_render_opt
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return NERF_OK;
 } NERF_CATCH(c)
+
+int nerf_band_rows(int window_rows, int band_index, int band_count, int band_stripe_rows) {
+    if (window_rows < 0 || band_count < 0 || band_stripe_rows < 0 || (band_count > 1 && (band_index < 0 || band_index >= band_count)))
+        return fail(nullptr, NERF_ERR_INVALID, "nerf_band_rows: bad argument");
+    return band_rows(window_rows, band_index, band_count, band_stripe_rows);
+}
 
 int nerf_kernel_time_query(nerf_ctx *c, double *ms, uint64_t *points, uint32_t *n_launches, int reset) try {
     if (!c) return fail(nullptr, NERF_ERR_INVALID, "ctx is NULL");

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -98,6 +99,15 @@ struct DeviceGuard { // a context is bound to one device; entry points may be ca
     }
     ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
 };
+
+// Rows of band i of n of a window of h rows (nerf_render_opts.band_*): stripe == 0 contiguous bands, stripe > 0 stripes round-robin.
+inline int band_rows(int h, int i, int n, int stripe) {
+    if (n <= 1) return h;
+    if (stripe <= 0) return h / n + (i < h % n ? 1 : 0);
+    const int full = h / stripe, tail = h % stripe;
+    return (full / n + (i < full % n ? 1 : 0)) * stripe + (tail > 0 && full % n == i ? tail : 0);
+}
+inline int band_first_row(int h, int i, int n) { return i * (h / n) + std::min(i, h % n); } // contiguous bands only
 
 int ensure_bytes(nerf_ctx *c, void **p, size_t *cur, size_t need);
 // render_image on the context's device, asynchronous on `st` (synchronises only when stats != NULL)

@@ -1,9 +1,15 @@
 // nerf_multi.cpp -- render_image over several GPUs of one node, behind the C ABI (no torch, no Python).
 //
 // The reference fans render_block out over rayon workers and scatters the blocks into one image
-// (src/lib.rs:533-557); every ray is independent.  Here the fan-out is over GPUs: context i (one per device) renders a
-// contiguous band of pixel rows -- its own host thread, its own stream, weights replicated -- and the bands meet in ONE
-// framebuffer.  Three ways to bring them together (nerf_gather):
+// (src/lib.rs:533-557); every ray is independent.  Here the fan-out is over GPUs: context i (one per device) renders band i of
+// the pixel rows -- its own host thread, its own stream, weights replicated -- and the bands meet in ONE framebuffer.
+// The partition (nerf_render_opts.band_*): rayon balances by work stealing; a static partition has to know where the cost is.
+//   * every ray costs the same (plain renders): CONTIGUOUS bands, the first rows % n one row longer;
+//   * the cost follows the scene (skip_dead, skip_empty, certify_zero: 75 % of the lego rays are background and nearly free there,
+//     and the background sits in the top rows): single rows dealt out ROUND-ROBIN -- neighbouring rows cost the same, so every
+//     band gets the same mix (tools/band_balance.py measures both partitions on one GPU).  The bands then arrive packed and a copy
+//     kernel (k_bands_to_frame) puts the rows where they belong; still ONE gather.
+// Three ways to bring the bands together (nerf_gather):
 //   HOST  every band goes device -> host straight into its rows of the caller's buffer (no GPU-to-GPU traffic);
 //   PEER  bands are copied GPU -> GPU over xGMI (hipMemcpyPeerAsync) into a frame on ctxs[0]'s device, one D2H from there;
 //   RCCL  one ncclAllGather of the bands over xGMI leaves the whole frame on EVERY device (the north-star's "RCCL gather
@@ -23,17 +29,11 @@
 #include <vector>
 
 #include "nerf_internal.h"
+#include "sampling_kernels.h"
 
 using namespace nerfint;
 
 namespace {
-
-// band_of_rank of nerf-rs_amd/distributed.py: contiguous, balanced; the first (rows % n) bands get one extra row
-void band_of(int rows, int i, int n, int *y0, int *h) {
-    const int base = rows / n, rem = rows % n;
-    *y0 = i * base + std::min(i, rem);
-    *h = base + (i < rem ? 1 : 0);
-}
 
 struct Rccl {
     void *lib = nullptr;
@@ -74,7 +74,8 @@ struct Job {
     nerf_render_opts o;  // this context's band as a crop window
     float *d_band;       // where the band is rendered (device memory of c->device)
     size_t band_floats;
-    size_t frame_off;    // float offset of the band inside the frame
+    size_t frame_off;    // float offset of the band inside the frame (contiguous bands)
+    int rows = 0;        // rows of the band
     nerf_stats *stats;
     int rc = NERF_OK;
 };
@@ -122,9 +123,10 @@ int nerf_render_image_multi(nerf_ctx *const *ctxs, int n, const nerf_camera *cam
     if (cw <= 0 || ch <= 0 || x0 < 0 || y0 < 0 || x0 + cw > cam->nx || y0 + ch > cam->ny)
         return fail(c0, NERF_ERR_INVALID, "crop window outside the frame");
     const size_t row_floats = (size_t)cw * 3, frame_floats = row_floats * ch;
-    int max_rows = 0, tmp = 0;
-    band_of(ch, 0, n, &tmp, &max_rows);
-    const size_t slot_floats = row_floats * max_rows; // RCCL: equal-sized slots, the ragged tail of a slot is unused
+    // cost follows the scene => rows round-robin (stripes of one row); uniform cost => contiguous bands
+    const int stripe = (n > 1 && (opts->skip_dead || opts->skip_empty || opts->certify_zero)) ? 1 : 0;
+    const int max_rows = band_rows(ch, 0, n, stripe);   // band 0 is never shorter than another band
+    const size_t slot_floats = row_floats * max_rows;   // RCCL / striped PEER: equal-sized slots, the ragged tail of a slot is unused
 
     // RCCL refuses two ranks on one device.  When contexts SHARE a device (single-GPU test boxes) the collective step of the RCCL
     // path is rehearsed as device-to-device copies into the same equal-slot buffers, so the slot layout, the stream ordering and the
@@ -151,27 +153,28 @@ int nerf_render_image_multi(nerf_ctx *const *ctxs, int n, const nerf_camera *cam
     }
 
     // Destination buffers.  HOST: each context's d_out holds its band.  PEER: ctxs[0]'s d_out holds the frame (its own band is
-    // rendered in place), the others hold their band.  RCCL: every d_out = n slots (the in-place all-gather buffer), then the
-    // frame is compacted behind them when the bands are ragged.
-    const bool ragged = (ch % n) != 0;
+    // rendered in place), the others hold their band -- striped: ctxs[0]'s d_out = n slots + the frame.  RCCL: every d_out = n slots
+    // (the in-place all-gather buffer), then the frame is assembled behind them when the bands are ragged or striped.
+    const bool ragged = (ch % n) != 0 || stripe > 0;
     std::vector<Job> jobs(n);
     for (int i = 0; i < n; ++i) {
         nerf_ctx *c = ctxs[i];
         DeviceGuard dg(c->device);
-        int b0 = 0, rows = 0;
-        band_of(ch, i, n, &b0, &rows);
+        const int rows = band_rows(ch, i, n, stripe), b0 = stripe ? 0 : band_first_row(ch, i, n);
         size_t need = row_floats * (size_t)std::max(rows, 1);
-        if (gather == NERF_GATHER_PEER && i == 0) need = frame_floats;
+        if (gather == NERF_GATHER_PEER && i == 0) need = stripe ? slot_floats * n + frame_floats : frame_floats;
         if (gather == NERF_GATHER_RCCL) need = slot_floats * n + (ragged ? frame_floats : 0);
         int rc;
         if ((rc = ensure_bytes(c, (void **)&c->d_out, &c->out_floats, need * sizeof(float)))) return rc;
         Job &J = jobs[i];
         J.c = c; J.o = *opts;
-        J.o.crop_x0 = x0; J.o.crop_y0 = y0 + b0; J.o.crop_w = cw; J.o.crop_h = rows;
+        J.o.crop_x0 = x0; J.o.crop_y0 = y0; J.o.crop_w = cw; J.o.crop_h = ch; // the caller's window; the band is selected by band_*
+        J.o.band_index = i; J.o.band_count = n; J.o.band_stripe_rows = stripe;
+        J.rows = rows;
         J.band_floats = row_floats * rows;
-        J.frame_off = row_floats * b0;
+        J.frame_off = row_floats * b0;                                          // contiguous bands only
         J.d_band = c->d_out;
-        if (gather == NERF_GATHER_PEER && i == 0) J.d_band = c->d_out + J.frame_off; // b0 == 0
+        if (gather == NERF_GATHER_PEER && i == 0) J.d_band = c->d_out + J.frame_off; // b0 == 0: the frame (contiguous) or slot 0 (striped)
         if (gather == NERF_GATHER_RCCL) J.d_band = c->d_out + slot_floats * i;
         J.stats = per_ctx ? &per_ctx[i] : nullptr;
         if (per_ctx) memset(&per_ctx[i], 0, sizeof(nerf_stats));
@@ -185,14 +188,22 @@ int nerf_render_image_multi(nerf_ctx *const *ctxs, int n, const nerf_camera *cam
         Job &J = jobs[i];
         nerf_ctx *c = J.c;
         if (hipSetDevice(c->device) != hipSuccess) { J.rc = fail(c, NERF_ERR_HIP, "hipSetDevice failed"); return; }
-        if (J.o.crop_h > 0) {
+        if (J.rows > 0) {
             J.rc = render_device(c, cam, &J.o, J.d_band, c->stream, J.stats);
             if (J.rc) return;
         }
         hipError_t e = hipSuccess;
-        if (gather == NERF_GATHER_HOST && J.band_floats)
-            e = hipMemcpyAsync(rgb_out + J.frame_off, J.d_band, J.band_floats * sizeof(float), hipMemcpyDeviceToHost, c->stream);
-        else if (gather == NERF_GATHER_PEER && i != 0 && J.band_floats) {
+        if (gather == NERF_GATHER_HOST && J.band_floats) {
+            if (!stripe) e = hipMemcpyAsync(rgb_out + J.frame_off, J.d_band, J.band_floats * sizeof(float), hipMemcpyDeviceToHost, c->stream);
+            else { // packed stripes -> every n-th stripe of the caller's frame: ONE strided copy (+ the frame's last, shorter stripe if it is ours)
+                const size_t sb = (size_t)stripe * row_floats * sizeof(float);
+                const int full = J.rows / stripe, tail = J.rows % stripe;
+                if (full) e = hipMemcpy2DAsync(rgb_out + (size_t)i * stripe * row_floats, sb * n, J.d_band, sb, sb, full, hipMemcpyDeviceToHost, c->stream);
+                if (e == hipSuccess && tail)
+                    e = hipMemcpyAsync(rgb_out + ((size_t)full * n + i) * stripe * row_floats, J.d_band + (size_t)full * stripe * row_floats,
+                                       (size_t)tail * row_floats * sizeof(float), hipMemcpyDeviceToHost, c->stream);
+            }
+        } else if (gather == NERF_GATHER_PEER && i != 0 && J.band_floats) {
             if (c->device != dev0) { // direct xGMI writes when the devices are peers (otherwise HIP stages the copy)
                 int can = 0;
                 if (hipDeviceCanAccessPeer(&can, c->device, dev0) == hipSuccess && can) {
@@ -200,7 +211,8 @@ int nerf_render_image_multi(nerf_ctx *const *ctxs, int n, const nerf_camera *cam
                     if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();
                 }
             }
-            e = hipMemcpyPeerAsync(d_frame0 + J.frame_off, dev0, J.d_band, c->device, J.band_floats * sizeof(float), c->stream);
+            // contiguous: straight to the band's place in the frame; striped: to slot i, the copy kernel below assembles the frame
+            e = hipMemcpyPeerAsync(d_frame0 + (stripe ? slot_floats * i : J.frame_off), dev0, J.d_band, c->device, J.band_floats * sizeof(float), c->stream);
         }
         if (e == hipSuccess && gather != NERF_GATHER_RCCL) e = hipStreamSynchronize(c->stream);
         if (e != hipSuccess) J.rc = fail(c, NERF_ERR_HIP, std::string("band gather: ") + hipGetErrorString(e));
@@ -273,7 +285,9 @@ int nerf_render_image_multi(nerf_ctx *const *ctxs, int n, const nerf_camera *cam
         for (int i = 0; i < n; ++i) {
             nerf_ctx *c = ctxs[i];
             DeviceGuard dg(c->device);
-            if (ragged && rc_first == NERF_OK) { // slots -> contiguous frame behind them (every device ends up with the whole frame)
+            if (stripe && rc_first == NERF_OK) // slots of packed rows -> frame behind them (every device ends up with the whole frame)
+                note(launch_bands_to_frame(c->d_out, c->d_out + slot_floats * n, cw, ch, n, stripe, slot_floats, c->stream), "bands -> frame");
+            else if (ragged && rc_first == NERF_OK) { // slots -> contiguous frame behind them (every device ends up with the whole frame)
                 float *frame = c->d_out + slot_floats * n;
                 for (int k = 0; k < n; ++k)
                     if (jobs[k].band_floats)
@@ -294,6 +308,10 @@ int nerf_render_image_multi(nerf_ctx *const *ctxs, int n, const nerf_camera *cam
     }
     if (gather == NERF_GATHER_PEER) {
         DeviceGuard dg(c0->device);
+        if (stripe) { // every band has arrived in its slot (the threads synchronised their streams): rows -> their places
+            HIP_TRY(c0, launch_bands_to_frame(c0->d_out, c0->d_out + slot_floats * n, cw, ch, n, stripe, slot_floats, c0->stream));
+            d_frame0 = c0->d_out + slot_floats * n;
+        }
         HIP_TRY(c0, hipMemcpyAsync(rgb_out, d_frame0, frame_floats * sizeof(float), hipMemcpyDeviceToHost, c0->stream));
         HIP_TRY(c0, hipStreamSynchronize(c0->stream));
     }

@@ -12,6 +12,9 @@ struct RayGenArgs {
     int normalize;   // 1: dir.normalize() (src/lib.rs:371)
     float sx, sy;    // tan(alpha_width), tan(alpha_height)
     float r[3], u[3], f[3]; // orthonormal basis (src/lib.rs:216-218), computed on the host
+    // striped bands (nerf_render_opts.band_*): stripe > 0 => ry0 counts BAND-LOCAL rows; band-local row j is ray-grid row
+    // stripe_y0 + ((j / stripe) * stripe_n + stripe_i) * stripe + j % stripe.  stripe == 0: ry0 is the ray-grid row itself.
+    int stripe, stripe_n, stripe_i, stripe_y0;
 };
 
 struct ResampleArgs {
@@ -57,6 +60,8 @@ hipError_t launch_stratified(const RayGenArgs &a, int count, float near_, float 
 hipError_t launch_resample(const ResampleArgs &a, hipStream_t st);
 hipError_t launch_composite(const CompositeArgs &a, hipStream_t st);
 hipError_t launch_box_downsample(const float *rays, float *out, int w, int h, int s, hipStream_t st);
+// multi-GPU: n gathered bands (slot_floats apart, rows packed) -> the h x w x 3 frame; stripe = 0: contiguous bands
+hipError_t launch_bands_to_frame(const float *slots, float *frame, int w, int h, int n, int stripe, size_t slot_floats, hipStream_t st);
 size_t resample_lds_bytes(int nc, int nf);
 size_t composite_lds_bytes(int n);
 // ---- zero certification (nerf_render_opts.certify_zero; kernels and protocol: sampling_kernels.hip) ------------------------------------

@@ -43,11 +43,19 @@ __device__ __forceinline__ void wave_sync() {
 
 } // namespace
 
+// Row of the (rny x rnx) ray grid that holds ray r of the pass: the pass's rows are consecutive rows of the window, or -- when the window's
+// rows are dealt out in stripes over several bands (nerf_render_opts.band_*; multi-GPU partitions that balance when the cost per ray is
+// not uniform) -- consecutive rows of THIS band: band-local row j is row stripe_y0 + ((j / stripe) * stripe_n + stripe_i) * stripe + j % stripe.
+__device__ __forceinline__ int ray_row(const RayGenArgs &a, int r) {
+    const int j = a.ry0 + r / a.rw;
+    return a.stripe > 0 ? a.stripe_y0 + ((j / a.stripe) * a.stripe_n + a.stripe_i) * a.stripe + j % a.stripe : j;
+}
+
 // ---- ray directions: one thread per ray of the pass rectangle ---------------------------------------
 __global__ void k_ray_dirs(RayGenArgs a, float *__restrict__ dirs) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= a.n_rays) return;
-    const int i = a.ry0 + r / a.rw, j = a.rx0 + r % a.rw;
+    const int i = ray_row(a, r), j = a.rx0 + r % a.rw;
     const float x = (((float)j + a.half) / (float)a.rnx) * 2.0f - 1.0f;
     const float y = 1.0f - (((float)i + a.half) / (float)a.rny) * 2.0f;
     const float xs = x * a.sx, ys = y * a.sy;
@@ -69,7 +77,7 @@ __global__ void k_stratified(RayGenArgs a, int count, float near_, float far_, u
     const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= (long long)a.n_rays * quads) return;
     const int r = (int)(gid / quads), q = (int)(gid % quads);
-    const uint32_t pix = (uint32_t)((a.ry0 + r / a.rw) * a.rnx + (a.rx0 + r % a.rw));
+    const uint32_t pix = (uint32_t)(ray_row(a, r) * a.rnx + (a.rx0 + r % a.rw));
     uint32_t rnd[4];
     philox4x32(seed_lo, seed_hi, pix, 0u, (uint32_t)q, 0u, rnd);
     const float interval = (far_ - near_) / (float)count;
@@ -158,7 +166,7 @@ __global__ __launch_bounds__(256) void k_resample(ResampleArgs a) {
     if (a.cdf_out) for (int i = lane; i <= m; i += 64) a.cdf_out[(size_t)ray * (nc - 1) + i] = cdf[i];
 
     const uint32_t pix = a.pixel_index ? a.pixel_index[ray]
-                                       : (uint32_t)((a.g.ry0 + ray / a.g.rw) * a.g.rnx + (a.g.rx0 + ray % a.g.rw));
+                                       : (uint32_t)(ray_row(a.g, ray) * a.g.rnx + (a.g.rx0 + ray % a.g.rw));
     // Hybrid sampling: a bound of |d cdf_j| at every bin edge j if this ray's densities carry the split arithmetics' error against the
     // f32 kernel (fitted and checked offline on dumped cases: tools/dump_hybrid_cases.py, tools/fit_hybrid_model.py).
     // The weights telescope -- sum_{i<=j} w_i = 1 - T_(j+1) -- so with the interior samples 1..j in front of edge j
@@ -592,6 +600,32 @@ hipError_t launch_cert_verify(const CertVerifyArgs &a, hipStream_t st) {
 hipError_t launch_cert_audit(const unsigned *aux, const unsigned *aux_count, unsigned aux_capacity, float *sigma, unsigned *audit, int n_cus, hipStream_t st) {
     if (aux_capacity == 0) return hipSuccess;
     hipLaunchKernelGGL(k_cert_audit, dim3(n_cus > 0 ? 2 * n_cus : 512), dim3(256), 0, st, aux, aux_count, aux_capacity, sigma, audit);
+    return hipGetLastError();
+}
+
+// ---- multi-GPU: bands -> frame ---------------------------------------------------------------------------------------------------
+// `slots` = n bands of slot_floats floats each (band b's rows packed at its start); band b holds the rows of the stripes b, b + n, ... of
+// the frame (stripe = `stripe` rows; stripe == 0: contiguous bands, the first h % n bands one row longer).  One thread per float4-less float:
+// the frame is 7.7 MB -- a copy kernel, HBM-bound.
+__global__ void k_bands_to_frame(const float *__restrict__ slots, float *__restrict__ frame, int w, int h, int n, int stripe, size_t slot_floats) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t row_floats = (size_t)w * 3;
+    if (idx >= row_floats * h) return;
+    const int y = (int)(idx / row_floats);
+    const size_t x = idx % row_floats;
+    int b, j;
+    if (stripe > 0) { const int k = y / stripe; b = k % n; j = (k / n) * stripe + y % stripe; }
+    else {
+        const int base = h / n, rem = h % n, split = rem * (base + 1);
+        if (y < split) { b = y / (base + 1); j = y % (base + 1); } else { b = rem + (y - split) / base; j = (y - split) % base; }
+    }
+    frame[idx] = slots[(size_t)b * slot_floats + (size_t)j * row_floats + x];
+}
+
+hipError_t launch_bands_to_frame(const float *slots, float *frame, int w, int h, int n, int stripe, size_t slot_floats, hipStream_t st) {
+    const size_t total = (size_t)w * 3 * h;
+    if (total == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_bands_to_frame, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, slots, frame, w, h, n, stripe, slot_floats);
     return hipGetLastError();
 }
 

@@ -66,6 +66,43 @@ def test_multi_with_skip_dead_and_hybrid_sampling(native, renderer, samples, thr
         assert np.array_equal(native.render_image_multi(three[:n], cam, 128, gather=gather, seed=0, crop=crop, skip_dead=True), plain)
 
 
+@pytest.mark.parametrize("stripe", [0, 1, 3])
+def test_band_option_renders_the_documented_rows(native, renderer, samples, stripe):
+    """nerf_render_opts.band_*: band i of n holds exactly the rows band_row_indices lists, packed, with the bits of the whole-window
+    render -- contiguous bands and stripes, with SSAA (stripes of whole pixel rows), with the modes whose cost follows the scene."""
+    cam = native.camera_from_samples(samples, 800, 800, 64)
+    crop = (250, 310, 120, 23)
+    for kw in (dict(), dict(ssaa=2, dtype="bf16"), dict(certify_zero=True), dict(skip_dead=True, dtype="f16x2")):
+        ref = native.render_image(renderer.coarse, renderer.fine, cam, 128, seed=9, crop=crop, **kw)
+        for n in (2, 5):
+            for i in range(n):
+                img, st = native.render_image(renderer.coarse, renderer.fine, cam, 128, seed=9, crop=crop, band=(i, n, stripe), return_stats=True, **kw)
+                rows = native.band_row_indices(23, i, n, stripe)
+                assert img.shape == (len(rows), 120, 3) and np.array_equal(img, ref[rows]), (kw, n, i)
+                assert st.n_rays == len(rows) * 120 * kw.get("ssaa", 1) ** 2
+    with pytest.raises(native.NerfError, match="no rows"):
+        native.render_image(renderer.coarse, renderer.fine, cam, 128, crop=(0, 0, 8, 2), band=(2, 3, 1))
+    with pytest.raises(native.NerfError, match="out of range"):
+        native.render_image(renderer.coarse, renderer.fine, cam, 128, crop=(0, 0, 8, 8), band=(3, 3, 1))
+
+
+@pytest.mark.parametrize("gather", ["host", "peer", "rccl"])
+def test_striped_partition_for_the_modes_whose_cost_follows_the_scene(native, renderer, samples, three, gather):
+    """skip_dead / skip_empty / certify_zero deal single rows out round-robin (the lego background is nearly free there and sits in the
+    top rows): the bands arrive packed and are put in place -- one strided D2H (host), slots + a copy kernel (peer, rccl).  Ragged
+    (101 rows over 2 and 3), more contexts than rows, and the plain frame's bits throughout."""
+    cam = native.camera_from_samples(samples, 800, 800, 64)
+    crop = (200, 300, 400, 101)
+    ref = native.render_image(renderer.coarse, renderer.fine, cam, 128, seed=0, crop=crop)
+    for n in (2, 3):
+        for kw in (dict(certify_zero=True), dict(skip_dead=True), dict(skip_empty=True)):
+            img, st = native.render_image_multi(three[:n], cam, 128, gather=gather, seed=0, crop=crop, return_stats=True, **kw)
+            assert np.array_equal(img, ref), (n, kw)
+            assert [s.n_rays for s in st] == [400 * native.band_rows(101, i, n, 1) for i in range(n)]
+    two = native.render_image(renderer.coarse, renderer.fine, cam, 128, seed=0, crop=(200, 300, 400, 2))
+    assert np.array_equal(native.render_image_multi(three, cam, 128, gather=gather, seed=0, crop=(200, 300, 400, 2), certify_zero=True), two)
+
+
 def test_multi_whole_frame_three_contexts(native, renderer, samples, three):
     cam = native.camera_from_samples(samples, 800, 800, 64)
     ref = native.render_image(renderer.coarse, renderer.fine, cam, 128, seed=0)

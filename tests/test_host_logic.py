@@ -454,7 +454,7 @@ def test_struct_sizes_match_the_library(native):
     L = native.load_library()
     a, b, c = C.c_size_t(), C.c_size_t(), C.c_size_t()
     L.nerf_abi_struct_sizes(C.byref(a), C.byref(b), C.byref(c))
-    assert (a.value, b.value, c.value) == (C.sizeof(_lib.CCamera), C.sizeof(_lib.COpts), C.sizeof(_lib.CStats)) == (60, 64, 160)
+    assert (a.value, b.value, c.value) == (C.sizeof(_lib.CCamera), C.sizeof(_lib.COpts), C.sizeof(_lib.CStats)) == (60, 72, 160)
 
 
 def test_loader_rejects_a_directory_named_like_a_tensor(native, tmp_path):
@@ -471,12 +471,29 @@ def test_render_opts_mirror_maps_every_field(native):
     from nerf_rs_amd.api import RenderOpts, _DTYPES
     assert (_DTYPES["f32"], _DTYPES["bf16"], _DTYPES["bf16x3"], _DTYPES["f16x2"]) == (0, 1, 2, 3)
     o = RenderOpts(n_coarse=40, n_fine=50, coarse_only=True, crop=(1, 2, 3, 4), ssaa=2, seed=(1 << 40) + 7, dtype="f16x2",
-                   skip_empty=True, skip_dead=True, hybrid_sampling=True, certify_zero=True).to_c()
+                   skip_empty=True, skip_dead=True, hybrid_sampling=True, certify_zero=True, band=(2, 5, 1)).to_c()
     got = {name: getattr(o, name) for name, _ in type(o)._fields_}
     assert got == {"n_coarse": 40, "n_fine": 50, "coarse_only": 1, "crop_x0": 1, "crop_y0": 2, "crop_w": 3, "crop_h": 4, "ssaa": 2,
-                   "seed": (1 << 40) + 7, "mlp_dtype": 3, "skip_empty": 1, "skip_dead": 1, "hybrid_sampling": 1, "certify_zero": 1}
+                   "seed": (1 << 40) + 7, "mlp_dtype": 3, "skip_empty": 1, "skip_dead": 1, "hybrid_sampling": 1, "certify_zero": 1,
+                   "band_index": 2, "band_count": 5, "band_stripe_rows": 1}
     z = RenderOpts().to_c()
-    assert (z.n_coarse, z.n_fine, z.mlp_dtype, z.skip_empty, z.skip_dead, z.hybrid_sampling, z.crop_w, z.ssaa) == (64, 128, 0, 0, 0, 0, 0, 1)
+    assert (z.n_coarse, z.n_fine, z.mlp_dtype, z.skip_empty, z.skip_dead, z.hybrid_sampling, z.crop_w, z.ssaa, z.band_count) == (64, 128, 0, 0, 0, 0, 0, 1, 0)
+
+
+def test_band_partitions_cover_the_window_once(native):
+    """nerf_band_rows (the C side) and band_row_indices (the layout the bands are packed in) agree, and every partition -- contiguous,
+    stripes of 1, 3, 8 rows -- deals every row of the window out exactly once, in frame order within a band."""
+    for h in (1, 7, 8, 61, 100, 800, 801):
+        for n in (1, 2, 3, 4, 8, 11):
+            for stripe in (0, 1, 3, 8):
+                rows = [native.band_row_indices(h, i, n, stripe) for i in range(n)]
+                assert [len(r) for r in rows] == [native.band_rows(h, i, n, stripe) for i in range(n)]
+                assert sorted(np.concatenate(rows).tolist()) == list(range(h))
+                assert all((np.diff(r) > 0).all() for r in rows)
+                assert len(rows[0]) == max(len(r) for r in rows)     # equal-slot gathers size their slots by band 0
+                if stripe == 1 or stripe == 0:
+                    assert max(len(r) for r in rows) - min(len(r) for r in rows) <= 1
+    assert native.load_library().nerf_band_rows(10, 3, 3, 0) < 0 and native.load_library().nerf_band_rows(-1, 0, 1, 0) < 0
 
 
 def test_loader_refuses_a_variant_build(native, tmp_path):

@@ -33,10 +33,12 @@ def fuzz(renderers, budget, rng_seed):
         crop = (int(rng.integers(0, W - w + 1)), int(rng.integers(0, H - h + 1)), w, h)
         ssaa = 2 if rng.integers(5) == 0 else 1
         dtype = ["f32", "f32", "bf16x3", "f16x2", "bf16"][int(rng.integers(5))]
-        mode = int(rng.integers(4))
+        mode = int(rng.integers(5))
         kw = dict(seed=int(rng.integers(0, 1 << 30)), crop=crop, ssaa=ssaa, dtype=dtype, coarse_only=(nf == 0))
         if mode == 1:
             kw["skip_empty"] = True
+        elif mode == 4 and dtype != "bf16":
+            kw["certify_zero"] = True     # (with skip_empty / skip_dead: rows round-robin instead of contiguous bands)
         elif mode >= 2:
             kw["skip_dead"] = True
             if mode == 3 and dtype != "bf16" and nf > 0:
