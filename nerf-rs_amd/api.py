@@ -291,7 +291,8 @@ def render_image(coarse, fine, camera, fine_samples_per_ray=128, *, seed=0, coar
         return Stats(st) if return_stats else None
     shape = opts.out_shape(camera)
     if shape[0] <= 0 or shape[1] <= 0:
-        raise NerfError(-1, "crop window outside the frame")
+        raise NerfError(-1, "this band has no rows (more bands than rows)" if opts.band and opts.band[1] > 1 and shape[1] > 0 and
+                        (crop[3] if crop else camera.ny) > 0 else "crop window outside the frame")
     out = np.empty(shape, np.float32)
     check(R._L.nerf_render_image(R.handle, C.byref(camera.c), C.byref(o), _p(out), C.byref(st)), R.handle)
     return (out, Stats(st)) if return_stats else out
