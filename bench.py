@@ -143,6 +143,94 @@ def launch_ranks(n, argv, script=None):
         raise SystemExit(f"bench.py: rank {failed[0]} exited with code {failed[1]}")
 
 
+def main_inproc(args):
+    """--launch inproc: time nerf_render_image_multi -- N contexts in THIS process (one per GPU; fewer GPUs than contexts: they share
+    device 0 and the line says so), bands on per-context host threads + streams, ONE gather (host / peer / rccl).  This is the path a
+    Rust host takes; torch is not imported.  The entry point hands back a HOST frame, so `value` here includes
+    the frame's device-to-host copy (7.68 MB; the per-rank launch keeps the frame in HBM) -- stated in `config.frame`."""
+    import ctypes as C
+    import nerf_rs_amd as N
+    n = args.gpus
+    n_dev = C.c_int(0)
+    if C.CDLL("libamdhip64.so").hipGetDeviceCount(C.byref(n_dev)) != 0 or n_dev.value < 1:
+        raise SystemExit("bench.py needs an MI355X: no HIP device is visible (there is no CPU fallback)")
+    distinct = n_dev.value >= n
+    scene = os.path.join(ROOT, "lego_rust")
+    rs = [N.Renderer(i if distinct else 0) for i in range(n)]
+    for r in rs:
+        r.load_scene(scene)
+    cam = N.camera_from_samples(os.path.join(scene, "tf_reference_samples.json"), args.width, args.height, args.coarse)
+    kw = dict(gather=args.gather, seed=args.seed, ssaa=args.ssaa, dtype=args.dtype, skip_empty=args.skip_empty, skip_dead=args.skip_dead,
+              hybrid_sampling=args.hybrid_sampling, certify_zero=args.certify_zero)
+    for _ in range(args.warmup):
+        N.render_image_multi(rs, cam, args.fine, **kw)
+    for r in rs:
+        r.kernel_time_query(reset=True)
+    walls, stats = [], None
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        t1 = time.perf_counter()
+        img, stats = N.render_image_multi(rs, cam, args.fine, return_stats=True, **kw)   # synchronous: returns with the frame on the host
+        walls.append(1e3 * (time.perf_counter() - t1))
+    dt = time.perf_counter() - t0
+    dom = [r.kernel_time_query(reset=True) for r in rs]
+    one = None
+    if n > 1:  # the same frame from one context: the bits must be the same
+        one = N.render_image(rs[0].coarse, rs[0].fine, cam, args.fine, **{k: v for k, v in kw.items() if k != "gather"})
+    import numpy as np
+    n_rays = args.width * args.height * args.ssaa * args.ssaa
+    flop_ray = N.flop_per_ray(args.coarse, args.fine)
+    bf16, split = args.dtype == "bf16", args.dtype in ("bf16x3", "f16x2")
+    peak = PEAK_BF16_MFMA_TFLOPS if (bf16 or split) else PEAK_FP32_MFMA_TFLOPS
+    mfma_per_flop = 6.0 if args.dtype == "bf16x3" else 3.0 if args.dtype == "f16x2" else 1.0
+    ms_dom = sum(d[0] for d in dom); n_dom = sum(d[2] for d in dom)
+    plain = not (args.skip_empty or args.skip_dead or args.certify_zero)
+    # plain renders: every sample of every band goes through the dominant (fine-network) kernel once per step; the sum of the launches'
+    # durations over all contexts prices the per-GPU rate (contexts that share a device run their launches one after another)
+    flops_dom = n_rays * (args.coarse + args.fine) * args.steps * N.FLOP_PER_POINT_FULL
+    ach = mfma_per_flop * flops_dom / (ms_dom * 1e-3) / 1e12 if (plain and ms_dom > 0) else None
+    renders = [s.ms_total for s in stats]
+    stripe = N.partition_for(args.skip_empty, args.skip_dead, args.certify_zero) if n > 1 else 0
+    line = {
+        "metric": "rays/sec, lego 800x800 (64 coarse + 128 fine samples per ray)", "value": n_rays * args.steps / dt, "unit": "rays/s",
+        "n_gpus": n, "launch": "inproc: nerf_render_image_multi (C ABI, one process, one context + host thread + stream per GPU)",
+        "gather": args.gather,
+        "backend": ((("RCCL ncclAllGather (grouped, in place) over xGMI" if args.gather == "rccl" else
+                      "hipMemcpyPeerAsync over xGMI into context 0's frame" if args.gather == "peer" else "per-band device-to-host copies")
+                     if distinct or n == 1 else
+                     f"REHEARSAL: {n} contexts share {n_dev.value} GPU(s) -- no speed-up to expect; " +
+                     ("the RCCL path's slot layout with the collective step as device-to-device copies (RCCL refuses two ranks on one device)"
+                      if args.gather == "rccl" else "same-device peer copies" if args.gather == "peer" else "per-band device-to-host copies"))),
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "strong",
+        "vs_baseline": None, "dtype": args.dtype, "data": "real lego weights + tf_reference_samples.json camera; sample positions from the seeded counter RNG",
+        "config": {"workload": f"C3/C4-style: lego coarse+fine hierarchical, {args.width}x{args.height}, {args.coarse}+{args.fine} samples/ray, {args.dtype}, "
+                               f"{n} context(s) in one process",
+                   "partition": "rows round-robin (band_stripe_rows = 1)" if stripe else "contiguous row bands",
+                   "rays_per_step": n_rays, "flop_per_ray": flop_ray, "seed": args.seed,
+                   "frame": "this entry point returns the frame in a HOST buffer: the timed region includes its device-to-host copy (7.68 MB at 800x800), unlike "
+                            "the per-rank launch whose `value` leaves the frame in HBM",
+                   "skip_empty": bool(args.skip_empty), "skip_dead": bool(args.skip_dead), "hybrid_sampling": bool(args.hybrid_sampling),
+                   "certify_zero": bool(args.certify_zero),
+                   "whole_job_fraction_of_mfma_roofline": mfma_per_flop * (n_rays * args.steps / dt) * flop_ray / ((n if distinct else 1) * peak * 1e12)},
+        "per_ctx": {"ms_render": {"max": max(renders), "min": min(renders), "by_ctx": renders},   # device time of each band, last step (nerf_stats.ms_total)
+                    "ms_step_wall": {"mean": sum(walls) / len(walls), "by_step": walls},
+                    # wall time of the last step beyond its slowest band: the gather, the frame's D2H and the host threads.  Not attributable
+                    # when contexts share a device (their kernels interleave, a band's device time then includes its neighbours' work)
+                    "ms_gather_and_host": (walls[-1] - max(renders)) if (distinct or n == 1) else None,
+                    "rays_by_ctx": [s.n_rays for s in stats],
+                    "ms_dominant_kernel_by_ctx": [d[0] / max(args.steps, 1) for d in dom]},
+        "image_bit_identical_to_one_context": (bool(np.array_equal(img, one)) if one is not None else None),
+    }
+    if ach is not None:
+        line["roofline"] = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s per GPU", "frac": ach / peak, "traffic": None,
+                            "kernel": "fine-network MLP launch of every band (HIP events on each context's stream; sum over contexts)", "launches": n_dom,
+                            "avg_launch_ms": ms_dom / max(n_dom, 1)}
+    print(json.dumps(line), flush=True)
+    for r in rs:
+        r.close()
+    N.load_library().nerf_multi_release()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -172,11 +260,19 @@ def main():
     ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
                     help="N > 1: strong = ONE frame split in row bands + one RCCL all-gather (SURVEY 8e, default); weak = every rank "
                          "renders a whole frame of its own view (independent frames of a camera path, no data-path collective)")
+    ap.add_argument("--launch", choices=["ranks", "inproc"], default="ranks",
+                    help="ranks (default, the driver's contract): one process per GPU, torch.distributed over RCCL.  inproc: ONE process, one "
+                         "context per GPU behind the C ABI -- nerf_render_image_multi, the call a Rust host makes (INTEGRATION.md section 2); "
+                         "no torch involved.  On a box with fewer GPUs than --gpus the contexts share device 0 and the line says REHEARSAL")
+    ap.add_argument("--gather", choices=["host", "peer", "rccl"], default="rccl",
+                    help="--launch inproc: how the bands meet (NERF_GATHER_HOST / _PEER / _RCCL)")
     ap.add_argument("--no-extra", action="store_true", help="skip the separately reported skip_empty frames (profiling runs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-cpu-reference-order", action="store_true",
                     help="quick runs: time only the oracle's cache-blocked nest (skips the ~2 min reference-loop-order sample)")
     args = ap.parse_args()
+    if args.launch == "inproc":
+        return main_inproc(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return launch_ranks(args.gpus, sys.argv[1:])
 

@@ -252,7 +252,7 @@ def band_rows(window_rows, index, count, stripe_rows=0):
     """Rows of band `index` of `count` (nerf_band_rows): stripe_rows = 0 contiguous bands, > 0 stripes of that many rows round-robin."""
     n = _lib.load_library().nerf_band_rows(int(window_rows), int(index), int(count), int(stripe_rows))
     if n < 0:
-        raise NerfError(n, "nerf_band_rows: bad argument")
+        raise NerfError(n, "band_index / band_count / band_stripe_rows out of range")
     return n
 
 

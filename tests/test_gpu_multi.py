@@ -196,6 +196,23 @@ def test_bench_self_launches_two_ranks_on_this_gpu():
     assert pr["ms_render"]["max"] + pr["ms_gather"]["max"] <= 1.5 * d["ms_per_step"] + 50   # the marks bracket the step's own work
 
 
+@pytest.mark.parametrize("gather,extra", [("rccl", []), ("peer", ["--certify-zero"]), ("host", ["--skip-dead"])])
+def test_bench_inproc_times_the_c_abi_multi_entry_point(gather, extra):
+    """`bench.py --launch inproc --gather G --gpus 2`: the timed call is nerf_render_image_multi (what a Rust host calls), two contexts
+    on this box's one GPU -- labelled a rehearsal -- and the frame must be the one-context frame bit for bit."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--launch", "inproc", "--gather", gather, "--gpus", "2", "--steps", "2",
+                        "--warmup", "1", "--width", "96", "--height", "81"] + extra, capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][0])
+    assert d["n_gpus"] == 2 and d["launch"].startswith("inproc") and d["gather"] == gather and "REHEARSAL" in d["backend"]
+    assert d["image_bit_identical_to_one_context"] is True and d["value"] > 0
+    assert d["config"]["partition"] == ("contiguous row bands" if not extra else "rows round-robin (band_stripe_rows = 1)")
+    pc = d["per_ctx"]
+    assert pc["rays_by_ctx"] == [96 * 41, 96 * 40] and len(pc["ms_render"]["by_ctx"]) == 2 and pc["ms_render"]["min"] > 0
+    assert ("roofline" in d) == (not extra)               # executed-flop accounting of the skip modes is the per-rank bench's business
+
+
 def test_bench_rccl_paths_at_world_size_one():
     """The RCCL (torch "nccl") collective of bench.py's N > 1 path, driven at world size 1 on this box's one GPU: (a) the direct
     init_process_group("nccl") the 8-GPU run takes, (b) the branch for launchers that give every rank ONE visible GPU -- identities
