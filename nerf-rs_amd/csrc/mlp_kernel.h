@@ -83,6 +83,11 @@ struct SeqArgs {
     const unsigned int *ray_list_count;
     int zero_fill_after_cut;
     unsigned int *nonfinite;   // optional (split arithmetics): += points whose density pre-activation is NaN / inf
+    // certify_zero's pre-filter (bf16 trunk only, export_live = false): store the density PRE-activation instead of sigma and retire a ray
+    // once its bf16 transmittance falls below prefilter_cut_T (a prediction: kept below the reference's 1e-4 so that k_cert_plan's own
+    // predicted cut always falls inside the evaluated samples).  The caller fills sigma_out with NaN (0xFF bytes): "not evaluated".
+    int prefilter;
+    float prefilter_cut_T;
 };
 struct ColourArgs {
     const float *wstream;      // the same stream (bottleneck + viewdirs part is used)

@@ -591,6 +591,28 @@ __device__ __forceinline__ void chunk_finish_bf16(mlpseq::RayWork &W, const SeqA
 }
 } // namespace
 
+// certify_zero's pre-filter (SeqArgs.prefilter): the raw pre-activation leaves the kernel (how far below 0 it is decides whether the exact
+// kernel looks at the sample at all), and the ray is retired where the bf16 transmittance predicts the cut -- nothing is exported.
+__device__ __forceinline__ void chunk_finish_prefilter(mlpseq::RayWork &W, const SeqArgs &A, const mlpseq::ChunkIn &c, float pre, int p, int h) {
+    using namespace mlpseq;
+    const int M = A.samples_per_ray;
+    if (c.valid && h == 0) A.sigma_out[c.base + c.s] = pre;
+    float delta = (c.s + 1 < M) ? c.t_next - c.t : A.far_ - c.t;
+    if (delta < 0.0f) delta = 0.0f;
+    const float alpha = c.valid ? 1.0f - expf(-fmaxf(pre, 0.f) * delta) : 0.0f;
+    float T = W.T;
+    bool cut = false;
+#pragma unroll
+    for (int k = 0; k < 32; ++k) {
+        const float al = lane_value(alpha, k);
+        T = cut ? T : T * (1.0f - al);
+        cut = cut || T < A.prefilter_cut_T;
+    }
+    W.T = T;
+    if (c.has) { const int left = M - 32 * W.chunk; W.samples_done += (unsigned)(left < 32 ? left : 32); }
+    chunk_advance(W, A, c, cut, p, h);
+}
+
 template <bool EXPORT>
 __global__ __launch_bounds__(256, 1) void nerf_trunk_seq_kernel_bf16(const SeqArgs A) {
     using namespace mlpseq;
@@ -633,8 +655,14 @@ __global__ __launch_bounds__(256, 1) void nerf_trunk_seq_kernel_bf16(const SeqAr
 #pragma unroll
         for (int c = 0; c < 3; ++c) H.rgb[0][c] = H.rgb[1][c] = 0.f;
         trunk_layers<EXPORT>(E0, E1, X0, X1, Y0, Y1, C, small, H, P, h);
-        const float s0 = fmaxf(xhalf_sum(H.alpha[0]) + small[kMiscOff + 0], 0.f);
-        const float s1 = fmaxf(xhalf_sum(H.alpha[1]) + small[kMiscOff + 0], 0.f);
+        const float pre0 = xhalf_sum(H.alpha[0]) + small[kMiscOff + 0], pre1 = xhalf_sum(H.alpha[1]) + small[kMiscOff + 0];
+        if (!EXPORT && A.prefilter) { // wave-uniform
+            chunk_finish_prefilter(W0, A, c0, pre0, p, h);
+            chunk_finish_prefilter(W1, A, c1, pre1, p, h);
+            continue;
+        }
+        const float s0 = fmaxf(pre0, 0.f);
+        const float s1 = fmaxf(pre1, 0.f);
         chunk_finish_bf16<EXPORT>(W0, A, c0, s0, Y0, lane, p, h);
         chunk_finish_bf16<EXPORT>(W1, A, c1, s1, Y1, lane, p, h);
     }

@@ -460,7 +460,9 @@ int render_once(nerf_ctx *c, const nerf_camera *cam, const nerf_render_opts *o, 
     // A certified sample has sigma = 0 => weight 0, a sample behind the cut has weight 0 whatever its density: the frame is the plain
     // frame, bit for bit, as long as no certificate is wrong.
     const bool certify = o->certify_zero != 0;
-    constexpr int kCertSlots = 8; // per (pass, network): {list 1 length, list 2 length, audited, violations, headroom code, max-error bits, fallback rays, audit-record count}
+    // per (pass, network): {list 1 length, list 2 length, audited, violations, headroom code, max-error bits, fallback rays, audit-record count,
+    //                       pre-filter ray queue head, -, u64 samples the pre-filter evaluated, ...}
+    constexpr int kCertSlots = 16;
     size_t aux_cap = 0;
     size_t cert_cap = 0;
     if (certify) {
@@ -555,7 +557,18 @@ int render_once(nerf_ctx *c, const nerf_camera *cam, const nerf_render_opts *o, 
             const int kind_side = which == 0 && !rgb_out ? 0 : 4;
             {
                 Timed t(c, st, kind_side, 0, timing);
-                HIP_TRY(c, launch_mlp(c, NERF_MLP_BF16, b, false, st));
+                if (c->cert_seq_prefilter) {
+                    // the pre-filter walks each ray front to back and stops where its own (bf16) transmittance predicts the cut, a little
+                    // later than k_cert_plan will (depth + 0.5): samples it never reaches stay NaN = "not evaluated" = uncertain
+                    HIP_TRY(c, hipMemsetAsync(sigma_out, 0xFF, (size_t)n_pts * sizeof(float), st));
+                    SeqArgs q{};
+                    q.wstream = stream_of(net, NERF_MLP_BF16); q.small_params = net.small; q.n_rays = n_rays; q.samples_per_ray = spr;
+                    q.ray_dirs = c->d_dirs; q.t = t_in; q.far_ = cam->far_;
+                    q.origin[0] = cam->pos[0]; q.origin[1] = cam->pos[1]; q.origin[2] = cam->pos[2];
+                    q.sigma_out = sigma_out; q.ray_counter = slots + 8; q.stats = (unsigned long long *)(slots + 10);
+                    q.prefilter = 1; q.prefilter_cut_T = expf(-(c->cert_depth_limit + 0.5f));
+                    HIP_TRY(c, nerf_trunk_seq_bf16_launch(q, false, c->n_cus, st));
+                } else HIP_TRY(c, launch_mlp(c, NERF_MLP_BF16, b, false, st));
                 CertPlanArgs p{};
                 p.pre = sigma_out; p.t = t_in; p.n_rays = n_rays; p.spr = spr; p.far_ = cam->far_;
                 p.margin = c->cert_margin[which]; p.depth_limit = c->cert_depth_limit;
@@ -872,6 +885,7 @@ int nerf_create(int device_id, nerf_ctx **out) try {
         if (v >= 0.0 && v <= 1.0) c->hybrid_tau = (float)v;
     }
 #ifdef NERF_CERT_TUNING // variant builds only (make variant DEFS=-DNERF_CERT_TUNING=1): the product's certificates are not configurable from the environment
+    if (const char *env = getenv("NERF_CERTIFY_SEQ_PREFILTER")) c->cert_seq_prefilter = atoi(env) != 0;
     if (const char *env = getenv("NERF_CERTIFY_CUT_DEPTH")) { const double v = atof(env); if (v > 0.0) c->cert_depth_limit = (float)v; }
     if (const char *env = getenv("NERF_CERTIFY_AUDIT_MASK")) { const long v = atol(env); if (v >= 0 && ((v + 1) & v) == 0) c->cert_audit_mask = (unsigned)v; }
     if (const char *env = getenv("NERF_CERTIFY_MARGINS")) {
