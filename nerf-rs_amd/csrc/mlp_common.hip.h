@@ -177,11 +177,20 @@ __device__ __forceinline__ void rgb_head(const Tiles &V, const LDS_AS float *sma
 struct RawIn { float a, b, c, dx, dy, dz; };
 
 // MLP_MODE_LIST: the list's length lives on the device; n_points is its CAPACITY (entries beyond it were counted, not stored: the host
-// renders such a frame again with a larger list, nerf_api.cpp)
+// renders such a frame again with a larger list, nerf_api.cpp).  The list has a front part growing up from entry 0 and an optional back
+// part growing down from entry n_points - 1 (MlpArgs.point_list_count_back).
+template <class Args>
+__device__ __forceinline__ void list_parts(const Args &A, unsigned &front, unsigned &back) {
+    const unsigned cap = (unsigned)A.n_points, nf = *A.point_list_count;
+    front = nf < cap ? nf : cap;
+    back = 0;
+    if (A.point_list_count_back) { const unsigned nb = *A.point_list_count_back; back = nb < cap - front ? nb : cap - front; }
+}
 template <class Args>
 __device__ __forceinline__ int list_length(const Args &A) {
-    const unsigned n = *A.point_list_count;
-    return (int)(n < (unsigned)A.n_points ? n : (unsigned)A.n_points);
+    unsigned f, b;
+    list_parts(A, f, b);
+    return (int)(f + b);
 }
 
 template <int MODE, class Args>
@@ -190,10 +199,13 @@ __device__ __forceinline__ RawIn load_raw(const Args &A, int tile_idx, int wave,
     RawIn r;
     int i = tile_idx * kPointsPerBlock + wave * kPointsPerWave + p;
     if (MODE == 2) { // slot i of a device-side sample list: entry = sample index | (audited certificate ? 1 << 31 : 0)
-        const int n = list_length(A);
+        unsigned nfront, nback;
+        list_parts(A, nfront, nback);
+        const int n = (int)(nfront + nback);
         r.a = 0.f; r.b = 0.f; r.c = 0.f; r.dx = 0.f; r.dy = 0.f; r.dz = 1.f;
         if (n <= 0) return r;
-        const unsigned entry = A.point_list[i < n ? i : n - 1];
+        const unsigned slot = (unsigned)(i < n ? i : n - 1);
+        const unsigned entry = A.point_list[slot < nfront ? slot : (unsigned)A.n_points - nback + (slot - nfront)];
         const unsigned idx = entry & 0x7fffffffu;
         const unsigned ray = idx / (unsigned)A.samples_per_ray;
         r.a = A.t[idx]; r.b = __builtin_bit_cast(float, entry);

@@ -30,6 +30,10 @@ struct MlpArgs {
     // outputs are scattered to the sample's own position; n_points = capacity of the list, *point_list_count = its length)
     const unsigned int *point_list;
     const unsigned int *point_list_count;
+    // optional second part of the list, filled from the END of the same buffer downwards (entry k at n_points - 1 - k): certify_zero puts the
+    // listed samples that are probably zeros there (and the audited certificates), so that their tiles are all-zero and skip_empty skips
+    // their colour heads.  Slots [0, front) map to entries [0, front), slots [front, front + back) to the last `back` entries.
+    const unsigned int *point_list_count_back;
 };
 
 // Sets the dynamic-LDS attribute of every kernel instantiation on the current device.

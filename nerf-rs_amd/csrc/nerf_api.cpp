@@ -461,7 +461,7 @@ int render_once(nerf_ctx *c, const nerf_camera *cam, const nerf_render_opts *o, 
     // frame, bit for bit, as long as no certificate is wrong.
     const bool certify = o->certify_zero != 0;
     // per (pass, network): {list 1 length, list 2 length, audited, violations, headroom code, max-error bits, fallback rays, audit-record count,
-    //                       pre-filter ray queue head, -, u64 samples the pre-filter evaluated, ...}
+    //                       pre-filter ray queue head, list 1 back-part length, u64 samples the pre-filter evaluated, ...}
     constexpr int kCertSlots = 16;
     size_t aux_cap = 0;
     size_t cert_cap = 0;
@@ -490,7 +490,7 @@ int render_once(nerf_ctx *c, const nerf_camera *cam, const nerf_render_opts *o, 
         nerf_ctx *c; bool ok = false;
         ~RenderScope() { if (!ok) for (auto &p : c->last_render) if (p.kind == 1) p.kind = 2; }
     } scope{c};
-    if (o->skip_empty && c->d_skip) HIP_TRY(c, hipMemsetAsync(c->d_skip, 0, sizeof(unsigned long long), st));
+    if ((o->skip_empty || certify) && c->d_skip) HIP_TRY(c, hipMemsetAsync(c->d_skip, 0, sizeof(unsigned long long), st));
     const bool watch_range = c->d_nonfinite && (split_dtype(dtype) || split_dtype(dtype_coarse));
     if (watch_range) HIP_TRY(c, hipMemsetAsync(c->d_nonfinite, 0, sizeof(unsigned int), st));
     const bool timing = true;
@@ -574,6 +574,10 @@ int render_once(nerf_ctx *c, const nerf_camera *cam, const nerf_render_opts *o, 
                 p.margin = c->cert_margin[which]; p.depth_limit = c->cert_depth_limit;
                 p.audit_mask = c->cert_audit_mask; p.audit_salt = (unsigned)(o->seed * 0x9E3779B97F4A7C15ull >> 32) + 0x632BE5ABu * passes + (unsigned)which;
                 p.list = c->d_point_list; p.count = slots; p.capacity = cap; p.jstar = c->d_jstar;
+                // full evaluations: probable zeros (bf16 pre-activation below -margin / 3: three times the largest bf16 error the lego audits see
+                // is not needed for a skip -- a positive density among them only keeps its tile's colour heads) and the audited certificates go
+                // to the back part of the list, whose all-zero tiles skip the colour head (exact: skip_empty)
+                if (rgb_out && c->cert_zero_tiles) { p.count_back = slots + 9; p.zero_threshold = c->cert_margin[which] * (1.0f / 3.0f); }
                 p.aux = c->d_cert_aux; p.aux_count = slots + 7; p.aux_capacity = (unsigned)aux_cap;
                 HIP_TRY(c, launch_cert_plan(p, st));
                 if (rgb_out) HIP_TRY(c, hipMemsetAsync(rgb_out, 0, (size_t)n_pts * 3 * sizeof(float), st)); // weight 0 either way: 0 * 0
@@ -582,6 +586,7 @@ int render_once(nerf_ctx *c, const nerf_camera *cam, const nerf_render_opts *o, 
             MlpArgs l = b;
             l.wstream = stream_of(net, dt); l.raw_pre = 0; l.mode = MLP_MODE_LIST; l.rgb_out = rgb_out; l.n_points = (int)cap;
             l.point_list = c->d_point_list; l.point_list_count = slots;
+            if (rgb_out && c->cert_zero_tiles) { l.point_list_count_back = slots + 9; l.skip_empty = 1; l.skip_counter = c->d_skip; }
             l.nonfinite = split_dtype(dt) ? c->d_nonfinite : nullptr;
             if (cap > 0) {
                 // points = 0: the list's length is known on the device only (nerf_stats.n_exec_* report it after the frame)
@@ -595,7 +600,7 @@ int render_once(nerf_ctx *c, const nerf_camera *cam, const nerf_render_opts *o, 
             v.t = t_in; v.sigma = sigma_out; v.n_rays = n_rays; v.spr = spr; v.far_ = cam->far_; v.jstar = c->d_jstar;
             v.list = c->d_point_list; v.count = slots + 1; v.capacity = cap; v.fallback_rays = slots + 6;
             HIP_TRY(c, launch_cert_verify(v, st));
-            l.point_list_count = slots + 1;
+            l.point_list_count = slots + 1; l.point_list_count_back = nullptr;
             if (cap > 0) HIP_TRY(c, launch_mlp(c, dt, l, rgb_out != nullptr, st)); // usually an empty list: the launch returns at once
             t.done(c->last_render);
             return NERF_OK;
@@ -702,8 +707,8 @@ int render_once(nerf_ctx *c, const nerf_camera *cam, const nerf_render_opts *o, 
             const int w = (int)(k & 1);
             if (w == 1 && o->coarse_only) continue;
             cert->used[w] = true;
-            cert->listed[w] += std::min<uint64_t>(q[0], cert->list_capacity) + std::min<uint64_t>(q[1], cert->list_capacity);
-            cert->list_need = std::max<uint64_t>(cert->list_need, std::max(q[0], q[1]));
+            cert->listed[w] += std::min<uint64_t>((uint64_t)q[0] + q[9], cert->list_capacity) + std::min<uint64_t>(q[1], cert->list_capacity);
+            cert->list_need = std::max<uint64_t>(cert->list_need, std::max<uint64_t>((uint64_t)q[0] + q[9], q[1]));
             cert->audited[w] += q[2]; cert->violations[w] += q[3];
             if (q[2]) {
                 const unsigned bits = 0x7f800000u - q[4];
@@ -743,7 +748,7 @@ int render_once(nerf_ctx *c, const nerf_camera *cam, const nerf_render_opts *o, 
             HIP_TRY(c, hipMemcpy(&bad, c->d_nonfinite, sizeof bad, hipMemcpyDeviceToHost));
             stats->n_nonfinite_points = bad;
         }
-        if (o->skip_empty && c->d_skip) {
+        if ((o->skip_empty || certify) && c->d_skip) { // certify_zero: all-zero tiles of the list's back part (probable zeros, audited certificates)
             unsigned long long tiles = 0;
             HIP_TRY(c, hipMemcpy(&tiles, c->d_skip, sizeof tiles, hipMemcpyDeviceToHost));
             stats->n_colour_skipped_points = (uint64_t)tiles * nerfmlp::kPointsPerBlock;
@@ -755,7 +760,7 @@ int render_once(nerf_ctx *c, const nerf_camera *cam, const nerf_render_opts *o, 
         if (certify && cert) { // samples the exact kernel evaluated = the lengths of the lists (audited certificates included)
             stats->n_exec_coarse_trunk = cert->listed[0];
             stats->n_exec_fine_trunk = o->coarse_only ? 0 : cert->listed[1];
-            stats->n_exec_colour = o->coarse_only ? cert->listed[0] : cert->listed[1];
+            stats->n_exec_colour = (o->coarse_only ? cert->listed[0] : cert->listed[1]) - std::min<uint64_t>(stats->n_colour_skipped_points, o->coarse_only ? cert->listed[0] : cert->listed[1]);
             stats->n_certify_audited = cert->audited[0] + cert->audited[1];
             stats->n_certify_violations = cert->violations[0] + cert->violations[1];
             stats->n_certify_fallback_rays = (uint32_t)std::min<uint64_t>(cert->fallback_rays, 0xffffffffu);
@@ -886,6 +891,7 @@ int nerf_create(int device_id, nerf_ctx **out) try {
     }
 #ifdef NERF_CERT_TUNING // variant builds only (make variant DEFS=-DNERF_CERT_TUNING=1): the product's certificates are not configurable from the environment
     if (const char *env = getenv("NERF_CERTIFY_SEQ_PREFILTER")) c->cert_seq_prefilter = atoi(env) != 0;
+    if (const char *env = getenv("NERF_CERTIFY_ZERO_TILES")) c->cert_zero_tiles = atoi(env) != 0;
     if (const char *env = getenv("NERF_CERTIFY_CUT_DEPTH")) { const double v = atof(env); if (v > 0.0) c->cert_depth_limit = (float)v; }
     if (const char *env = getenv("NERF_CERTIFY_AUDIT_MASK")) { const long v = atol(env); if (v >= 0 && ((v + 1) & v) == 0) c->cert_audit_mask = (unsigned)v; }
     if (const char *env = getenv("NERF_CERTIFY_MARGINS")) {

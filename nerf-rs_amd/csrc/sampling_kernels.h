@@ -77,6 +77,10 @@ struct CertPlanArgs {
     unsigned *list;      // phase-1 list: sample index | (audit ? 1 << 31 : 0)
     unsigned *count;     // += entries (also those beyond capacity)
     unsigned capacity;
+    // optional back part of the list (entry k at capacity - 1 - k): the listed samples that are PROBABLY zeros -- pre-activation below
+    // -zero_threshold -- and the audited certificates; count_back = NULL: everything goes to the front part
+    unsigned *count_back;
+    float zero_threshold;
     unsigned *aux;       // {sample index, bits of its bf16 pre-activation} of every audited certificate
     unsigned *aux_count;
     unsigned aux_capacity;

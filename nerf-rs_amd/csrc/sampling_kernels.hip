@@ -427,7 +427,8 @@ __global__ __launch_bounds__(256) void k_cert_plan(CertPlanArgs a) {
     unsigned *stage = lds_u + (size_t)wv * per_wave;
     unsigned *aux_stage = stage + (size_t)a.rays_per_wave * spr;
     const int ray0 = (blockIdx.x * 4 + wv) * a.rays_per_wave;
-    unsigned staged = 0, n_aux = 0; // wave-uniform
+    unsigned staged = 0, staged_back = 0, n_aux = 0; // wave-uniform
+    const unsigned stage_cap = (unsigned)a.rays_per_wave * (unsigned)spr;
     for (int rr = 0; rr < a.rays_per_wave; ++rr) {
         const int ray = ray0 + rr;
         if (ray >= a.n_rays) break; // wave-uniform
@@ -462,18 +463,23 @@ __global__ __launch_bounds__(256) void k_cert_plan(CertPlanArgs a) {
             const unsigned aux_at = n_aux + (unsigned)__popcll(am & ((1ull << lane) - 1ull));
             audit = audit && aux_at < (unsigned)kAuxStage; // no room to remember its bf16 value: certified without audit, like its 63 siblings
             const bool listed = (in && !dead && unc) || audit;
+            // probable zeros (and the audited certificates, which are zeros unless the certificate is wrong) are staged from the END of the
+            // wave's area downwards and leave for the back part of the list: tiles of zeros skip their colour heads (skip_empty)
+            const bool to_back = listed && a.count_back && (audit || pre < -a.zero_threshold);
             if (in) a.pre[base + i] = (dead && unc) ? kCertMarker : 0.0f;
-            const unsigned long long lm = __ballot(listed);
-            const unsigned at = staged + (unsigned)__popcll(lm & ((1ull << lane) - 1ull));
+            const unsigned long long lm = __ballot(listed && !to_back), bm = __ballot(to_back);
+            const unsigned at = to_back ? stage_cap - 1u - (staged_back + (unsigned)__popcll(bm & ((1ull << lane) - 1ull)))
+                                        : staged + (unsigned)__popcll(lm & ((1ull << lane) - 1ull));
             if (listed) stage[at] = (unsigned)(base + i) | (audit ? 0x80000000u : 0u);
             if (audit) { aux_stage[2 * aux_at] = at; aux_stage[2 * aux_at + 1] = __float_as_uint(pre); }
             staged += (unsigned)__popcll(lm);
+            staged_back += (unsigned)__popcll(bm);
             n_aux = n_aux + (unsigned)__popcll(am);
             n_aux = n_aux < (unsigned)kAuxStage ? n_aux : (unsigned)kAuxStage;
         }
         if (lane == 0) a.jstar[ray] = jstar;
     }
-    if (staged == 0) return; // wave-uniform
+    if (staged + staged_back == 0) return; // wave-uniform
     wave_sync();
     if (n_aux) { // remember {sample, bf16 pre-activation} of the audited certificates; one that does not fit is not audited (flag cleared)
         unsigned at_aux = 0;
@@ -486,11 +492,20 @@ __global__ __launch_bounds__(256) void k_cert_plan(CertPlanArgs a) {
         }
         wave_sync();
     }
-    unsigned at = 0;
-    if (lane == 0) at = atomicAdd(a.count, staged);
-    at = (unsigned)__builtin_amdgcn_readfirstlane((int)at);
-    for (unsigned k = lane; k < staged; k += 64)
-        if (at + k < a.capacity) a.list[at + k] = stage[k];
+    if (staged) {
+        unsigned at = 0;
+        if (lane == 0) at = atomicAdd(a.count, staged);
+        at = (unsigned)__builtin_amdgcn_readfirstlane((int)at);
+        for (unsigned k = lane; k < staged; k += 64)
+            if (at + k < a.capacity) a.list[at + k] = stage[k];
+    }
+    if (staged_back) { // (front and back parts meet only in a frame whose list is too short: the host renders that frame again)
+        unsigned at = 0;
+        if (lane == 0) at = atomicAdd(a.count_back, staged_back);
+        at = (unsigned)__builtin_amdgcn_readfirstlane((int)at);
+        for (unsigned k = lane; k < staged_back; k += 64)
+            if (at + k < a.capacity) a.list[a.capacity - 1u - (at + k)] = stage[stage_cap - 1u - k];
+    }
 }
 
 // Exact transmittance over [0, j*) of every ray with a predicted cut (j* < spr): one wave per ray, alpha in parallel, the recurrence as

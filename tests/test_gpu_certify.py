@@ -29,7 +29,7 @@ def test_c3_whole_frame_is_the_f32_frame(renderer, native, samples):
           f"the coarse and {ff:.3f} of the fine samples; audited {st.n_certify_audited}, violations {st.n_certify_violations}, headroom "
           f"{st.certify_headroom} at margins {st.certify_margin}, {st.n_certify_fallback_rays} of {st.n_rays} rays fell back, {st.n_certify_retries} retries")
     # work fractions only (timing ratios are bench output: a throttled box must not turn a correctness suite red)
-    assert 0.1 < fc < 0.45 and 0.08 < ff < 0.3 and st.n_exec_colour == st.n_exec_fine_trunk
+    assert 0.1 < fc < 0.45 and 0.08 < ff < 0.3 and 0.6 * st.n_exec_fine_trunk < st.n_exec_colour < st.n_exec_fine_trunk   # probable zeros and audited certificates skip the colour head tile-wise
     assert st.n_certify_retries == 0 and st.n_certify_violations == 0 and st.certify_margin == (1.5, 3.0)
     certified = st.n_coarse_points + st.n_fine_points - st.n_exec_coarse_trunk - st.n_exec_fine_trunk
     assert 0.5 * certified / 64 < st.n_certify_audited < 1.5 * certified / 64 + 1000   # audited certificates in front of the predicted cuts (most certified samples)
