@@ -477,6 +477,7 @@ def main():
         extra_cert = {"rays_per_s": n_r / (ms * 1e-3), "ms_per_step": ms, "image_bit_identical_to_headline_run": identical,
                       "f32_evaluated_fraction_coarse": st.n_exec_coarse_trunk / max(st.n_coarse_points, 1),
                       "f32_evaluated_fraction_fine": st.n_exec_fine_trunk / max(st.n_fine_points, 1),
+                      "colour_head_fraction_fine": st.n_exec_colour / max(st.n_fine_points, 1),
                       "device_ms": {"total": st.ms_total, "coarse_bf16_pass_plus_f32_list": st.ms_coarse_mlp, "fine_bf16_pass_plus_f32_list": st.ms_fine_mlp, "other": st.ms_other},
                       "audit": {"certified_samples_evaluated_all_the_same": st.n_certify_audited, "violations": st.n_certify_violations,
                                 "margins_coarse_fine": list(st.certify_margin), "least_headroom_coarse_fine": list(st.certify_headroom),
@@ -646,13 +647,15 @@ def main():
             # launch (colour passes on the LDS-compacted live samples); bf16 / split arithmetics: in a second launch, not priced here -- the colour head
             flops_dom = (n_dom / max(dead_stats.n_passes, 1)) * (dead_stats.n_exec_fine_trunk * N.FLOP_PER_POINT_SIGMA +
                                                                   (0 if two_launch else dead_stats.n_exec_colour * (N.FLOP_PER_POINT_FULL - N.FLOP_PER_POINT_SIGMA)))
-        if cert_stats is not None:  # dominant launch = the f32 list kernel of the fine network: full evaluations of the listed samples
-            flops_dom = n_dom * cert_stats.n_exec_fine_trunk * N.FLOP_PER_POINT_FULL
+        if cert_stats is not None:  # dominant launch = the list kernel of the fine network: trunk of the listed samples + the colour heads not skipped tile-wise
+            flops_dom = (n_dom / max(cert_stats.n_passes, 1)) * (cert_stats.n_exec_fine_trunk * N.FLOP_PER_POINT_SIGMA +
+                                                                  cert_stats.n_exec_colour * (N.FLOP_PER_POINT_FULL - N.FLOP_PER_POINT_SIGMA))
         ach = mfma_per_flop * flops_dom / (ms_dom * 1e-3) / 1e12 if ms_dom > 0 else 0.0
         traffic, traffic_src, traffic_why = pmc_traffic_bytes(
             (f"void nerf_trunk_seq_kernel_{sfx}<true" if two_launch else "void nerf_trunk_seq_kernel<true") if args.skip_dead else
-            "void nerf_mlp_kernel_bf16v2<true" if bf16 else "void nerf_mlp_kernel_bf16x3<true" if x3 else
-            "void nerf_mlp_kernel_f16x2<true" if x2 else "void nerf_mlp_kernel<true, 2" if args.certify_zero else "void nerf_mlp_kernel<true")
+            "void nerf_mlp_kernel_bf16v2<true" if bf16 else
+            ("void nerf_mlp_kernel_bf16x3<true, 2" if x3 else "void nerf_mlp_kernel_f16x2<true, 2" if x2 else "void nerf_mlp_kernel<true, 2") if args.certify_zero else
+            "void nerf_mlp_kernel_bf16x3<true" if x3 else "void nerf_mlp_kernel_f16x2<true" if x2 else "void nerf_mlp_kernel<true")
         line = {  # noqa: E501
             "metric": "rays/sec, lego 800x800 (64 coarse + 128 fine samples per ray)", "value": value, "unit": "rays/s",
             "n_gpus": world, "ranks": dist.get_world_size() if use_dist else 1,
@@ -688,7 +691,7 @@ def main():
                          "kernel": ((f"nerf_trunk_seq_kernel_{sfx}<EXPORT=true> (fine network, ray-sequential trunk; executed flops)" if two_launch else
                                      "nerf_trunk_seq_kernel<EXPORT=true> (fine network, ray-sequential trunk + in-kernel colour passes; executed flops)")
                                     if dead_stats is not None else
-                                    "nerf_mlp_kernel<FULL=true, MODE_LIST> (fine network, the samples a bf16 pass could not certify as zeros; executed flops)"
+                                    ("nerf_mlp_kernel" + ("_bf16x3" if x3 else "_f16x2" if x2 else "") + "<FULL=true, MODE_LIST> (fine network, the samples a bf16 pass could neither certify as zeros nor place behind the cut; executed flops)")
                                     if cert_stats is not None else
                                     ("nerf_mlp_kernel_bf16v2" if bf16 else "nerf_mlp_kernel_bf16x3" if x3 else "nerf_mlp_kernel_f16x2" if x2 else "nerf_mlp_kernel") +
                                     "<FULL=true, MODE_RAYS> (fine network)"),
