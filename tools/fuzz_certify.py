@@ -32,7 +32,13 @@ def fuzz(r, budget, rng_seed):
         kw = dict(seed=int(rng.integers(0, 1 << 30)), crop=(int(rng.integers(0, W - w + 1)), int(rng.integers(0, W - h + 1)), w, h),
                   ssaa=2 if rng.integers(6) == 0 else 1, coarse_only=(nf == 0))
         kw["dtype"] = str(rng.choice(["f32", "f32", "f16x2", "bf16x3"]))  # split arithmetics: f32 certified coarse pass + certified fine pass
-        ref = N.render_image(r.coarse, r.fine, cam, nf, **kw)
+        try:
+            ref = N.render_image(r.coarse, r.fine, cam, nf, **kw)
+        except N.NerfError as e:   # a hot network may leave the f16 range: that arithmetic fails loudly by design, with or without certify_zero
+            if e.code == -6 and kw["dtype"] == "f16x2" and "left the range" in e.msg:
+                tot["f16_range_errors"] = tot.get("f16_range_errors", 0) + 1
+                continue
+            raise
         img, st = N.render_image(r.coarse, r.fine, cam, nf, certify_zero=True, return_stats=True, **kw)
         tot["cases"] += 1; tot["rays"] += st.n_rays
         tot["f32_samples_nominal"] += st.n_coarse_points + st.n_fine_points
