@@ -112,7 +112,7 @@ typedef struct {
                            * (Z) rests on measurements, not on a proof, so it is AUDITED in every frame: one certified sample in 64 is evaluated
                            * exactly all the same; a positive density there (nerf_stats.n_certify_violations), or an audited sample on which the bf16
                            * pass was off by more than half the margin (nerf_stats.certify_max_error, certify_headroom), widens that network's margin for the life of
-                           * the context (floors: 1.5 coarse, 3.0 fine -- 4-8 x the largest bf16-vs-f32 difference seen on zero-density samples of
+                           * the context (floors: 1.0 coarse, 3.0 fine -- 2.5-5 x the largest bf16-vs-f32 difference the audits see on certified samples of
                            * the lego networks; reset when a network is loaded) and the frame is rendered again (nerf_stats.n_certify_retries); if
                            * 8 widenings do not satisfy the audit the render fails with NERF_ERR_STATE.  A network on which bf16 is less accurate
                            * thus calibrates itself, certifies nothing (random weights: pre-activations near 0), or fails loudly; what remains

@@ -29,8 +29,8 @@ def test_c3_whole_frame_is_the_f32_frame(renderer, native, samples):
           f"the coarse and {ff:.3f} of the fine samples; audited {st.n_certify_audited}, violations {st.n_certify_violations}, headroom "
           f"{st.certify_headroom} at margins {st.certify_margin}, {st.n_certify_fallback_rays} of {st.n_rays} rays fell back, {st.n_certify_retries} retries")
     # work fractions only (timing ratios are bench output: a throttled box must not turn a correctness suite red)
-    assert 0.1 < fc < 0.45 and 0.08 < ff < 0.3 and 0.6 * st.n_exec_fine_trunk < st.n_exec_colour < st.n_exec_fine_trunk   # probable zeros and audited certificates skip the colour head tile-wise
-    assert st.n_certify_retries == 0 and st.n_certify_violations == 0 and st.certify_margin == (1.5, 3.0)
+    assert 0.05 < fc < 0.45 and 0.08 < ff < 0.3 and 0.6 * st.n_exec_fine_trunk < st.n_exec_colour < st.n_exec_fine_trunk   # probable zeros and audited certificates skip the colour head tile-wise
+    assert st.n_certify_retries == 0 and st.n_certify_violations == 0 and st.certify_margin == (1.0, 3.0)
     certified = st.n_coarse_points + st.n_fine_points - st.n_exec_coarse_trunk - st.n_exec_fine_trunk
     assert 0.5 * certified / 64 < st.n_certify_audited < 1.5 * certified / 64 + 1000   # audited certificates in front of the predicted cuts (most certified samples)
     assert all(h >= 0.5 * m for h, m in zip(st.certify_headroom, st.certify_margin))
@@ -127,7 +127,7 @@ def _load(native, r, root):
 
 
 def test_hot_network_widens_its_margins_instead_of_differing(native, samples, tmp_path):
-    """Pre-activations 40 x the lego networks': bf16 is off by up to tens on zero-density samples, the shipped margins (1.5 / 3) certify
+    """Pre-activations 40 x the lego networks': bf16 is off by up to tens on zero-density samples, the shipped margins (1 / 3) certify
     samples whose exact density is positive.  The audit must see it (violations, or headroom below half the margin), widen the
     margins and render again: the frame returned is the plain frame of that network, and the next frame starts from the widened margins."""
     with native.Renderer(0) as r:
@@ -145,7 +145,7 @@ def test_hot_network_widens_its_margins_instead_of_differing(native, samples, tm
         assert np.array_equal(img2, native.render_image(r.coarse, r.fine, cam, 128, seed=4, crop=crop))
         _load(native, r, SCENE)  # loading a network resets its margin
         _, st3 = native.render_image(r.coarse, r.fine, cam, 128, seed=4, crop=crop, certify_zero=True, return_stats=True)
-        assert st3.certify_margin == (1.5, 3.0) and st3.n_certify_retries == 0 and st3.n_certify_violations == 0
+        assert st3.certify_margin == (1.0, 3.0) and st3.n_certify_retries == 0 and st3.n_certify_violations == 0
 
 
 def test_uncertifiable_network_fails_loudly_or_is_exact(native, samples, tmp_path):
@@ -185,4 +185,4 @@ def test_random_weight_fogs(native, samples, tmp_path, kw):
         assert st.n_certify_retries == (1 if W == 400 else 0)   # the list grew once (a fog lists every sample), no margin moved
         img2, st2 = native.render_image(r.coarse, r.fine, cam, 128, seed=6, certify_zero=True, return_stats=True)
         assert np.array_equal(img2, native.render_image(r.coarse, r.fine, cam, 128, seed=6))
-        assert st2.n_certify_retries == 0 and st2.certify_margin == st.certify_margin == (1.5, 3.0)
+        assert st2.n_certify_retries == 0 and st2.certify_margin == st.certify_margin == (1.0, 3.0)
