@@ -40,7 +40,8 @@ def test_c3_whole_frame_is_the_f32_frame(renderer, native, samples):
 @pytest.mark.parametrize("nc,nf,W,crop,coarse_only,ssaa,pose_deg", [
     (64, 128, 800, (300, 300, 200, 64), False, 1, None), (40, 50, 800, (380, 360, 40, 24), False, 1, None), (64, 0, 800, (200, 200, 300, 100), True, 1, None),
     (33, 31, 800, (0, 0, 800, 8), False, 1, None), (64, 128, 800, (395, 400, 1, 1), False, 1, None), (64, 128, 128, None, False, 2, None),
-    (64, 128, 200, None, False, 1, (130, 10)), (32, 64, 200, None, False, 1, (250, -20)), (3, 0, 64, None, True, 1, None)])
+    (64, 128, 200, None, False, 1, (130, 10)), (32, 64, 200, None, False, 1, (250, -20)), (3, 0, 64, None, True, 1, None),
+    (300, 500, 400, (180, 190, 40, 12), False, 1, None), (70, 1000, 400, (150, 200, 24, 6), False, 1, None)])   # 800 / 1070 samples per ray: several 256-sample batches per ray in k_cert_plan
 def test_windows_sample_counts_poses(renderer, native, samples, nc, nf, W, crop, coarse_only, ssaa, pose_deg):
     if pose_deg is None:
         cam = native.camera_from_samples(samples, W, W, nc)

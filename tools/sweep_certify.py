@@ -11,7 +11,7 @@ import nerf_rs_amd as N
 S = os.path.join(ROOT, "lego_rust", "tf_reference_samples.json")
 cam = N.camera_from_samples(S, 800, 800, 64)
 ref = None
-for depth, mask in [(11.51, 63), (10.5, 63), (10.0, 63), (9.7, 63), (9.5, 63), (9.35, 63), (9.25, 63), (9.5, 127), (9.5, 31)]:
+for depth, mask in [(4.0, 63), (7.0, 63), (8.5, 63), (11.51, 63), (10.5, 63), (10.0, 63), (9.7, 63), (9.5, 63), (9.35, 63), (9.25, 63), (9.5, 127), (9.5, 31)]:
     os.environ["NERF_CERTIFY_CUT_DEPTH"] = str(depth); os.environ["NERF_CERTIFY_AUDIT_MASK"] = str(mask)
     with N.Renderer(0) as r:
         r.load_scene(os.path.join(ROOT, "lego_rust"))
