@@ -115,12 +115,17 @@ int main(int argc, char **argv) {
                                              : opts.n_coarse * 982528.0 + (double)(opts.n_coarse + opts.n_fine) * 1186816.0;
     const bool bf16 = opts.mlp_dtype != NERF_MLP_F32;
     const double mfma_flops = opts.mlp_dtype == NERF_MLP_BF16X3 ? 6.0 : opts.mlp_dtype == NERF_MLP_F16X2 ? 3.0 : 1.0; // executed bf16 MFMA flops per algorithmic f32 flop
-    if (gpus > 1) printf("%d GPUs, row bands gathered by %s\n", gpus, gather == NERF_GATHER_PEER ? "xGMI peer copies" : gather == NERF_GATHER_RCCL ? "one RCCL all-gather" : "direct D2H");
+    if (gpus > 1) printf("%d GPUs, %s gathered by %s\n", gpus, (opts.skip_dead || opts.skip_empty || opts.certify_zero) ? "rows dealt out round-robin," : "contiguous row bands", gather == NERF_GATHER_PEER ? "xGMI peer copies" : gather == NERF_GATHER_RCCL ? "one RCCL all-gather" : "direct D2H");
     printf("device %s (%d CUs): %.0f rays/s (best of %d, host wall incl. D2H); device %.1f ms = coarse MLP %.1f + fine MLP %.1f + other %.1f; "
            "%.1f%% of the %s MFMA roofline\n",
            arch, n_cus, (double)st.n_rays / best, frames, st.ms_total, st.ms_coarse_mlp, st.ms_fine_mlp, st.ms_other,
            100.0 * mfma_flops * (double)st.n_rays * flop_ray / (st.ms_total * 1e-3) / (gpus * (bf16 ? 2500e12 : 157.3e12)),
            bf16 ? "2.5 PFLOP/s bf16" : "157.3 TFLOP/s fp32");
+    if (opts.certify_zero) // the audit of the last frame (first context): what the certificates rested on
+        printf("certify_zero audit: %llu certificates evaluated all the same, %llu violations, margins %.3g / %.3g, least headroom %.3g / %.3g, largest bf16 error %.3g / %.3g, "
+               "frame rendered again %u time(s), %u rays beyond their predicted cut\n", (unsigned long long)st.n_certify_audited, (unsigned long long)st.n_certify_violations,
+               (double)st.certify_margin[0], (double)st.certify_margin[1], (double)st.certify_headroom[0], (double)st.certify_headroom[1],
+               (double)st.certify_max_error[0], (double)st.certify_max_error[1], st.n_certify_retries, st.n_certify_fallback_rays);
     if (nerf_save_ppm(out.c_str(), ow, oh, image.data())) { fprintf(stderr, "error: %s\n", nerf_last_error(nullptr)); return 1; } // :676
     for (nerf_ctx *c : ctxs) nerf_destroy(c);
     return 0;
