@@ -577,7 +577,7 @@ int render_once(nerf_ctx *c, const nerf_camera *cam, const nerf_render_opts *o, 
                 // full evaluations: probable zeros (bf16 pre-activation below -margin / 3: three times the largest bf16 error the lego audits see
                 // is not needed for a skip -- a positive density among them only keeps its tile's colour heads) and the audited certificates go
                 // to the back part of the list, whose all-zero tiles skip the colour head (exact: skip_empty)
-                if (rgb_out && c->cert_zero_tiles) { p.count_back = slots + 9; p.zero_threshold = c->cert_margin[which] * (1.0f / 3.0f); }
+                if (rgb_out && c->cert_zero_tiles) { p.count_back = slots + 9; p.zero_threshold = c->cert_margin[which] * c->cert_zero_frac; }
                 p.aux = c->d_cert_aux; p.aux_count = slots + 7; p.aux_capacity = (unsigned)aux_cap;
                 HIP_TRY(c, launch_cert_plan(p, st));
                 if (rgb_out) HIP_TRY(c, hipMemsetAsync(rgb_out, 0, (size_t)n_pts * 3 * sizeof(float), st)); // weight 0 either way: 0 * 0
@@ -892,6 +892,7 @@ int nerf_create(int device_id, nerf_ctx **out) try {
 #ifdef NERF_CERT_TUNING // variant builds only (make variant DEFS=-DNERF_CERT_TUNING=1): the product's certificates are not configurable from the environment
     if (const char *env = getenv("NERF_CERTIFY_SEQ_PREFILTER")) c->cert_seq_prefilter = atoi(env) != 0;
     if (const char *env = getenv("NERF_CERTIFY_ZERO_TILES")) c->cert_zero_tiles = atoi(env) != 0;
+    if (const char *env = getenv("NERF_CERTIFY_ZERO_FRAC")) { const double v = atof(env); if (v > 0.0 && v <= 1.0) c->cert_zero_frac = (float)v; }
     if (const char *env = getenv("NERF_CERTIFY_CUT_DEPTH")) { const double v = atof(env); if (v > 0.0) c->cert_depth_limit = (float)v; }
     if (const char *env = getenv("NERF_CERTIFY_AUDIT_MASK")) { const long v = atol(env); if (v >= 0 && ((v + 1) & v) == 0) c->cert_audit_mask = (unsigned)v; }
     if (const char *env = getenv("NERF_CERTIFY_MARGINS")) {

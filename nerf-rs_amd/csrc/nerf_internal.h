@@ -69,6 +69,7 @@ struct nerf_ctx {
                                           // lego frame 0 rays fall back at 9.5, 25 at 9.35, 1132 of 640 000 at 9.25 -- tools/sweep_certify.py)
     unsigned cert_audit_mask = 63;        // one certified sample in 64 is audited
     bool cert_zero_tiles = true;          // probable zeros + audited certificates in the list's back part, evaluated with skip_empty
+    float cert_zero_frac = 0.1f;          // "probably zero": bf16 pre-activation below -margin x this (C3 frame: 1/2 -> 334.6 ms, 1/3 -> 333.1, 0.1 -> 330.5, 0.02 -> 331.0: tools/sweep_certify_zero_frac.py)
     bool cert_seq_prefilter = true;       // bf16 pre-filter ray-sequential with its own predicted cut (false: the fused bf16 kernel over all samples)
     double cert_list_frac = 0.5;          // list capacity as a fraction of a pass's samples: what earlier frames needed + 25 %
     float hybrid_tau = 1e-5f;                                        // a draw predicted to move by more than this (in t) flags its ray
