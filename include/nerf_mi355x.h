@@ -105,7 +105,7 @@ typedef struct {
                            * network's density is certainly 0 there as well, and predicts (C) where each ray's transmittance falls below the
                            * reference's 1e-4 cut (src/lib.rs:276-279: every later weight is zero-filled whatever its density).  The exact kernel
                            * -- for the fine pass of a split arithmetic that arithmetic's kernel -- evaluates only the other samples in front of
-                           * the predicted cut (a device-side list: 25-40 % of the coarse, 15-21 % of the fine samples of the lego frame); the
+                           * the predicted cut (a device-side list: 12 % of the coarse, 21 % of the fine samples of the lego frame); the
                            * EXACT transmittance then confirms each cut, and where it does not (rare) the rest of that ray is evaluated in a
                            * second launch -- so (C) is exact by construction.  A certified sample has sigma = 0, weight 0 (src/lib.rs:271-272):
                            * the image is BIT-IDENTICAL to certify_zero = 0 as long as no certificate (Z) is wrong.
