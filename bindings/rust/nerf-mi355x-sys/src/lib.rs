@@ -115,6 +115,7 @@ extern "C" {
                                        small_cap: usize, wstream_len: *mut usize, small_len: *mut usize) -> c_int;
     pub fn nerf_debug_split_bf16x3(values: *const f32, n: usize, parts: *mut u16) -> c_int;
     pub fn nerf_debug_split_f16x2(values: *const f32, n: usize, parts: *mut u16) -> c_int;
+    pub fn nerf_debug_certify_policy(margin: f32, audited: u64, violations: u64, headroom: f32, max_error: f32, new_margin: *mut f32) -> c_int;
     pub fn nerf_debug_shader_clock_mhz(ctx: *mut nerf_ctx, mhz: *mut f64) -> c_int;
     pub fn nerf_forward_batch(ctx: *mut nerf_ctx, which: c_int, pts_soa: *const f32, dirs_aos: *const f32, n: usize,
                               rgb_aos: *mut f32, sigma: *mut f32) -> c_int;

@@ -194,6 +194,11 @@ int nerf_debug_pack_network_dir(const char *dir, float *wstream, size_t wstream_
 /* Diagnostic: the three bf16 parts (raw bit patterns) the NERF_MLP_BF16X3 packer stores for each of n f32 weights:
  * parts[3 i + k], k = 0..2, with v = p0 + p1 + p2 up to 2^-27 |v|.  Host-only. */
 int nerf_debug_split_bf16x3(const float *values, size_t n, uint16_t *parts /* 3 n */);
+/* Diagnostic: certify_zero's audit policy as the renderer applies it after every certified frame, per network -- given the margin in force and
+ * what the audit found (audited certificates, violations among them, least headroom, largest |bf16 - exact| error: the nerf_stats fields),
+ * returns 0 if the frame stands, else 1 (a violation: margin x 4, or 4 x the error), 2 (headroom below half the margin: x 2, or 4 x the
+ * error) or 3 (error above half the margin: x 1.25, or 3 x the error) with the widened margin in *new_margin.  Host-only. */
+int nerf_debug_certify_policy(float margin, uint64_t audited, uint64_t violations, float headroom, float max_error, float *new_margin);
 /* The same for the NERF_MLP_F16X2 packer: two f16 parts (IEEE binary16 bit patterns), v = p0 + p1 up to 2^-22 |v|.  Host-only. */
 int nerf_debug_split_f16x2(const float *values, size_t n, uint16_t *parts /* 2 n */);
 
@@ -306,7 +311,7 @@ const char *nerf_build_variant(void);
 /* ABI version (currently 5): bumped on any signature or struct change (2: multi-GPU entry points, skip_dead, n_exec_* statistics; 3: nerf_stats.
  * n_nonfinite_points, nerf_check_network_blob, nerf_stage_hybrid_flags, nerf_build_variant; 4: nerf_render_opts.certify_zero; 5: nerf_stats.
  * n_certify_* / certify_margin / certify_headroom / certify_max_error, renders fail on n_nonfinite_points != 0,
- * nerf_render_opts.band_*, nerf_band_rows). */
+ * nerf_render_opts.band_*, nerf_band_rows, nerf_debug_certify_policy). */
 int nerf_abi_version(void);
 /* sizeof(nerf_camera), sizeof(nerf_render_opts), sizeof(nerf_stats) as this library was built: lets a binding written in
  * another language (the Rust `-sys` crate, ctypes) check its struct mirrors at start-up. */

@@ -65,6 +65,7 @@ PROTOTYPES = {
                                               C.POINTER(C.c_size_t)]),
     "nerf_debug_split_bf16x3": (C.c_int, [f32p, C.c_size_t, C.POINTER(C.c_uint16)]),
     "nerf_debug_split_f16x2": (C.c_int, [f32p, C.c_size_t, C.POINTER(C.c_uint16)]),
+    "nerf_debug_certify_policy": (C.c_int, [C.c_float, C.c_uint64, C.c_uint64, C.c_float, C.c_float, f32p]),
     "nerf_forward_batch": (C.c_int, [C.c_void_p, C.c_int, f32p, f32p, C.c_size_t, f32p, f32p]),
     "nerf_forward_batch_ex": (C.c_int, [C.c_void_p, C.c_int, C.c_int, f32p, f32p, C.c_size_t, f32p, f32p]),
     "nerf_forward_batch_device": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p,

@@ -7,6 +7,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <fstream>
 #include <sstream>
 
@@ -434,6 +435,19 @@ int save_ppm(const std::string &path, int width, int height, const float *rgb, s
     fclose(f);
     if (!ok) { err = "save_ppm: short write " + path; return NERF_ERR_IO; }
     return NERF_OK;
+}
+
+int certify_policy(float margin, uint64_t audited, uint64_t violations, float headroom, float max_error, float *new_margin) {
+    if (new_margin) *new_margin = margin;
+    if (!audited) return 0; // nothing was certified in front of a predicted cut: nothing to judge
+    const float m = margin, err = std::max(max_error, m - headroom);
+    float widened = m;
+    int rule = 0;
+    if (violations) { widened = std::max(4.0f * m, 4.0f * err); rule = 1; }
+    else if (!(headroom >= 0.5f * m)) { widened = std::max(2.0f * m, 4.0f * err); rule = 2; }
+    else if (!(err <= 0.5f * m)) { widened = std::max(1.25f * m, 3.0f * err); rule = 3; }
+    if (rule && new_margin) *new_margin = widened;
+    return rule;
 }
 
 } // namespace nerfhost

@@ -60,4 +60,12 @@ const char *last_error_noctx();
 int read_blob_file(const std::string &path, std::vector<float> &wstream, std::vector<float> &small, std::string &err);
 int save_ppm(const std::string &path, int width, int height, const float *rgb, std::string &err);
 
+// certify_zero's audit policy (nerf_api.cpp render_device; exposed host-only as nerf_debug_certify_policy so that it is tested without a
+// GPU).  Given what the audit of one network found in one frame, decide whether the frame stands and, if not, the widened margin:
+//   a violation (an audited certificate with a positive exact density)              -> max(4 m, 4 err)
+//   least headroom below m / 2 (an audited sample closer to a positive density)     -> max(2 m, 4 err)
+//   largest |bf16 - exact| on an audited certificate above m / 2                    -> max(1.25 m, 3 err)
+// err = max(largest error, m - least headroom).  Returns 0 (stands), 1 / 2 / 3 (which rule widened; *new_margin is set).
+int certify_policy(float margin, uint64_t audited, uint64_t violations, float headroom, float max_error, float *new_margin);
+
 } // namespace nerfhost

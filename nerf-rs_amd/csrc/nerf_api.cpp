@@ -820,12 +820,14 @@ int nerfint::render_device(nerf_ctx *c, const nerf_camera *cam, const nerf_rende
         if (!overflow) violations += oc.violations[0] + oc.violations[1];
         for (int w = 0; w < 2 && !overflow; ++w) {
             if (!oc.used[w] || !oc.audited[w]) continue;
-            const float m = c->cert_margin[w];
-            // what the bf16 pass got wrong on the samples it certified, as far as the audit saw: at the margin (m - headroom) and anywhere below it
-            const float err = std::max(oc.max_err[w], m - oc.headroom[w]);
-            if (oc.violations[w]) { c->cert_margin[w] = std::max(4.0f * m, 4.0f * err); again = true; why = "an audited certificate was wrong"; }
-            else if (!(oc.headroom[w] >= 0.5f * m)) { c->cert_margin[w] = std::max(2.0f * m, 4.0f * err); again = true; why = "an audited certificate came closer to a positive density than half the margin"; }
-            else if (!(err <= 0.5f * m)) { c->cert_margin[w] = std::max(1.25f * m, 3.0f * err); again = true; why = "the bf16 pass was off by more than half the margin on an audited certificate"; }
+            // the rules live in host_util.cpp (certify_policy: tested on the CPU through nerf_debug_certify_policy)
+            float widened = c->cert_margin[w];
+            const int rule = certify_policy(c->cert_margin[w], oc.audited[w], oc.violations[w], oc.headroom[w], oc.max_err[w], &widened);
+            if (rule) {
+                c->cert_margin[w] = widened; again = true;
+                why = rule == 1 ? "an audited certificate was wrong" : rule == 2 ? "an audited certificate came closer to a positive density than half the margin"
+                                                                                 : "the bf16 pass was off by more than half the margin on an audited certificate";
+            }
         }
         if (stats) { stats->n_certify_retries = (uint32_t)attempt; stats->n_certify_violations = violations; }
         if (!again) return NERF_OK;

@@ -112,6 +112,11 @@ int nerf_debug_split_bf16x3(const float *values, size_t n, uint16_t *parts) try 
     return NERF_OK;
 } NERF_HOST_CATCH
 
+int nerf_debug_certify_policy(float margin, uint64_t audited, uint64_t violations, float headroom, float max_error, float *new_margin) {
+    if (!(margin > 0.0f)) return fail_noctx(NERF_ERR_INVALID, "margin must be > 0");
+    return certify_policy(margin, audited, violations, headroom, max_error, new_margin);
+}
+
 int nerf_debug_split_f16x2(const float *values, size_t n, uint16_t *parts) try {
     if ((!values || !parts) && n) return fail_noctx(NERF_ERR_INVALID, "NULL argument");
     for (size_t i = 0; i < n; ++i) split_f16x2(values[i], parts + 2 * i);

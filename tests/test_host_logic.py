@@ -538,6 +538,41 @@ def test_abi_version_is_stated_consistently(native):
     assert not re.search(rf"\b{v + 1}: nerf_", h)
     rs = open(os.path.join(ROOT, "bindings", "rust", "nerf-mi355x-sys", "src", "lib.rs")).read()
     assert f"(ABI version {v})" in rs.splitlines()[0] and f"nerf_abi_version() }} == {v} " in rs and f"expects ABI {v} with" in rs
-    assert f"C ABI (ABI version {v})" in open(os.path.join(ROOT, "DESIGN.md")).read()
+    assert re.search(rf"C ABI \(ABI version {v}[):]", open(os.path.join(ROOT, "DESIGN.md")).read())
     assert f"`nerf_abi_version` ({v})" in open(os.path.join(ROOT, "INTEGRATION.md")).read()
     assert f"nerf_abi_version() == {v}" in open(os.path.join(ROOT, "__graft_entry__.py")).read()
+
+
+def test_certify_audit_policy(native):
+    """certify_zero's audit policy (host_util.cpp certify_policy, the function render_device applies after every certified frame), on the CPU:
+    a frame stands only if no audited certificate was wrong, the closest audited sample kept half the margin, and the bf16 pass was off by
+    at most half the margin on every audited certificate; every rule widens the margin enough that the same audit would pass afterwards."""
+    L = native.load_library()
+    inf = float("inf")
+
+    def policy(m, audited, viol, head, err):
+        out = C.c_float(-1.0)
+        return L.nerf_debug_certify_policy(m, audited, viol, head, err, C.byref(out)), out.value
+
+    assert policy(3.0, 1_700_000, 0, 2.39, 0.99) == (0, 3.0)                 # the lego fine network, C3 frame
+    assert policy(1.0, 50_000, 0, 0.96, 0.15) == (0, 1.0)                    # the coarse one
+    assert policy(3.0, 0, 0, inf, 0.0) == (0, 3.0)                           # nothing certified (a random-weight fog): nothing to judge
+    rule, m = policy(3.0, 1000, 2, 1.0, 29.0)                                # a wrong certificate: x 4, or 4 x the error seen
+    assert rule == 1 and m == pytest.approx(116.0)
+    assert policy(3.0, 1000, 1, 2.9, 0.2) == (1, 12.0)
+    rule, m = policy(3.0, 1000, 0, 1.2, 0.3)                                 # headroom 1.2 < 1.5: boundary error 1.8 -> 4 x 1.8
+    assert rule == 2 and m == pytest.approx(7.2)
+    rule, m = policy(3.0, 1000, 0, 2.9, 1.6)                                 # off by 1.6 > 1.5 somewhere below the margin -> 3 x 1.6
+    assert rule == 3 and m == pytest.approx(4.8)
+    assert policy(3.0, 1000, 0, 2.9, 1.5)[0] == 0                            # exactly half the margin still stands
+    assert policy(3.0, 1000, 0, 2.9, float("nan"))[0] == 3                   # a NaN statistic never lets a frame stand
+    # after a widening the same audit passes, and a hot network converges: errors scale with the network, margins follow
+    rng = np.random.default_rng(3)
+    for _ in range(200):
+        m0 = float(rng.uniform(0.5, 5)); err = float(rng.uniform(0, 50)); head = float(rng.uniform(-1, 1) * m0 + m0 * 0.5)
+        viol = int(rng.integers(0, 2)) if head < m0 else 0
+        rule, m1 = policy(m0, 1000, viol, head, err)
+        if rule:
+            assert m1 >= 1.25 * m0 and policy(m1, 1000, 0, m1 - min(err, m0 - head if head < m0 else 0.0), err)[0] in (0, 3)
+            assert policy(m1, 1000, 0, m1, min(err, 0.5 * m1))[0] == 0
+    assert L.nerf_debug_certify_policy(0.0, 1, 0, 1.0, 0.0, None) < 0
