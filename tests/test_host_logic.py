@@ -576,3 +576,9 @@ def test_certify_audit_policy(native):
             assert m1 >= 1.25 * m0 and policy(m1, 1000, 0, m1 - min(err, m0 - head if head < m0 else 0.0), err)[0] in (0, 3)
             assert policy(m1, 1000, 0, m1, min(err, 0.5 * m1))[0] == 0
     assert L.nerf_debug_certify_policy(0.0, 1, 0, 1.0, 0.0, None) < 0
+
+
+def test_one_file_variant_script_tags_its_library():
+    """tools/variant_one.sh (one kernel file rebuilt with tuning switches) must tag its library like `make variant` does: until round 4 it did not."""
+    src = open(os.path.join(ROOT, "tools", "variant_one.sh")).read()
+    assert "-DNERF_BUILD_VARIANT=" in src and "nerf_host_api.cpp" in src and "amdgpu-mfma-vgpr-form=1" in src
