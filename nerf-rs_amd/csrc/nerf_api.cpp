@@ -466,7 +466,7 @@ int render_once(nerf_ctx *c, const nerf_camera *cam, const nerf_render_opts *o, 
     size_t aux_cap = 0;
     size_t cert_cap = 0;
     if (certify) {
-        if (cert_plan_lds_bytes(M, nullptr) > 160 * 1024) return fail(c, NERF_ERR_INVALID, "certify_zero: too many samples per ray");
+        if (cert_plan_lds_bytes(M, nullptr) > 159 * 1024) return fail(c, NERF_ERR_INVALID, "certify_zero: too many samples per ray");
         const size_t n_pass = ((size_t)RH + rows_per_pass - 1) / rows_per_pass;
         const size_t pass_samples = rows_per_pass * RW * (size_t)M;
         // the list is sized from what earlier frames needed (c->cert_list_frac of the samples, +25 %): if a pass wants more, the entries

@@ -407,10 +407,11 @@ __global__ void k_box_downsample(const float *__restrict__ rays, float *__restri
 //   * samples [j*, spr): uncertain ones are only MARKED (kCertMarker in the buffer); k_cert_verify either clears the marks (the exact
 //     transmittance over [0, j*) did fall below 1e-4: the ray is decided) or lists them for a second exact launch (rare);
 //   * the buffer is zeroed otherwise: it becomes the exact pass's density buffer, whose listed entries the exact kernel overwrites.
-// List order is arbitrary (one atomic per wave per kPlanRays rays, entries staged in LDS); results do not depend on it.  The list has a
+// List order is arbitrary (one atomic per workgroup and list part, entries staged in LDS); results do not depend on it.  The list has a
 // CAPACITY: entries beyond it are counted, not stored -- the host sees count > capacity after the frame, grows the list and renders the
 // frame again (nerf_api.cpp).
 constexpr float kCertMarker = -1.0f;
+constexpr int kCertPlanMaxLds = 159 * 1024; // dynamic LDS of k_cert_plan (its reservation counters are static LDS on top)
 constexpr int kPlanRays = 8; // rays per wave between two flushes of its LDS staging area
 
 __device__ __forceinline__ bool cert_audit_pick(unsigned idx, unsigned salt, unsigned mask) {
@@ -487,12 +488,21 @@ __global__ __launch_bounds__(256) void k_cert_plan(CertPlanArgs a) {
         }
         if (lane == 0) a.jstar[ray] = jstar;
     }
+    // One reservation per WORKGROUP and list part: a same-address atomic costs ~7 ns at the L2 and they serialise -- one per wave was half of
+    // this kernel's 2 ms per 123 M samples.  Every wave of the block gets here (no early return above).
+    __shared__ unsigned s_cnt[4][3], s_base[3];
+    if (lane == 0) { s_cnt[wv][0] = staged; s_cnt[wv][1] = staged_back; s_cnt[wv][2] = n_aux; }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const unsigned total = s_cnt[0][threadIdx.x] + s_cnt[1][threadIdx.x] + s_cnt[2][threadIdx.x] + s_cnt[3][threadIdx.x];
+        unsigned *ctr = threadIdx.x == 0 ? a.count : threadIdx.x == 1 ? a.count_back : a.aux_count;
+        s_base[threadIdx.x] = (total && ctr) ? atomicAdd(ctr, total) : 0u;
+    }
+    __syncthreads();
+    unsigned at_front = s_base[0], at_back = s_base[1], at_aux = s_base[2];
+    for (int w = 0; w < wv; ++w) { at_front += s_cnt[w][0]; at_back += s_cnt[w][1]; at_aux += s_cnt[w][2]; }
     if (staged + staged_back == 0) return; // wave-uniform
-    wave_sync();
     if (n_aux) { // remember {sample, bf16 pre-activation} of the audited certificates; one that does not fit is not audited (flag cleared)
-        unsigned at_aux = 0;
-        if (lane == 0) at_aux = atomicAdd(a.aux_count, n_aux);
-        at_aux = (unsigned)__builtin_amdgcn_readfirstlane((int)at_aux);
         for (unsigned k = lane; k < n_aux; k += 64) {
             const unsigned sp = aux_stage[2 * k];
             if (at_aux + k < a.aux_capacity) { a.aux[2 * (size_t)(at_aux + k)] = stage[sp] & 0x7fffffffu; a.aux[2 * (size_t)(at_aux + k) + 1] = aux_stage[2 * k + 1]; }
@@ -500,20 +510,11 @@ __global__ __launch_bounds__(256) void k_cert_plan(CertPlanArgs a) {
         }
         wave_sync();
     }
-    if (staged) {
-        unsigned at = 0;
-        if (lane == 0) at = atomicAdd(a.count, staged);
-        at = (unsigned)__builtin_amdgcn_readfirstlane((int)at);
-        for (unsigned k = lane; k < staged; k += 64)
-            if (at + k < a.capacity) a.list[at + k] = stage[k];
-    }
-    if (staged_back) { // (front and back parts meet only in a frame whose list is too short: the host renders that frame again)
-        unsigned at = 0;
-        if (lane == 0) at = atomicAdd(a.count_back, staged_back);
-        at = (unsigned)__builtin_amdgcn_readfirstlane((int)at);
-        for (unsigned k = lane; k < staged_back; k += 64)
-            if (at + k < a.capacity) a.list[a.capacity - 1u - (at + k)] = stage[stage_cap - 1u - k];
-    }
+    for (unsigned k = lane; k < staged; k += 64)
+        if (at_front + k < a.capacity) a.list[at_front + k] = stage[k];
+    // (front and back parts meet only in a frame whose list is too short: the host renders that frame again)
+    for (unsigned k = lane; k < staged_back; k += 64)
+        if (at_back + k < a.capacity) a.list[a.capacity - 1u - (at_back + k)] = stage[stage_cap - 1u - k];
 }
 
 // Exact transmittance over [0, j*) of every ray with a predicted cut (j* < spr): one wave per ray, alpha in parallel, the recurrence as
@@ -606,7 +607,7 @@ hipError_t launch_cert_plan(const CertPlanArgs &a, hipStream_t st) {
     if (a.n_rays <= 0 || a.spr <= 0) return hipSuccess;
     CertPlanArgs b = a;
     const size_t lds = cert_plan_lds_bytes(a.spr, &b.rays_per_wave);
-    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    if (lds > (size_t)kCertPlanMaxLds) return hipErrorInvalidValue;
     const int rays_per_block = 4 * b.rays_per_wave;
     hipLaunchKernelGGL(k_cert_plan, dim3((a.n_rays + rays_per_block - 1) / rays_per_block), dim3(256), lds, st, b);
     return hipGetLastError();
@@ -674,7 +675,7 @@ size_t composite_lds_bytes(int) { return sizeof(float) * 64 * (2 * kCompTS + kCo
 
 hipError_t sampling_init(void) {
     hipError_t e = hipFuncSetAttribute((const void *)k_resample, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_cert_plan, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_cert_plan, hipFuncAttributeMaxDynamicSharedMemorySize, kCertPlanMaxLds); // (+ 60 B static)
     if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_cert_verify, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     return e;
 }
