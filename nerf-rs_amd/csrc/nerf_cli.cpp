@@ -116,11 +116,13 @@ int main(int argc, char **argv) {
     const bool bf16 = opts.mlp_dtype != NERF_MLP_F32;
     const double mfma_flops = opts.mlp_dtype == NERF_MLP_BF16X3 ? 6.0 : opts.mlp_dtype == NERF_MLP_F16X2 ? 3.0 : 1.0; // executed bf16 MFMA flops per algorithmic f32 flop
     if (gpus > 1) printf("%d GPUs, %s gathered by %s\n", gpus, (opts.skip_dead || opts.skip_empty || opts.certify_zero) ? "rows dealt out round-robin," : "contiguous row bands", gather == NERF_GATHER_PEER ? "xGMI peer copies" : gather == NERF_GATHER_RCCL ? "one RCCL all-gather" : "direct D2H");
+    const bool skips = opts.skip_dead || opts.skip_empty || opts.certify_zero; // then less than the algorithmic work is executed: not a roofline fraction
     printf("device %s (%d CUs): %.0f rays/s (best of %d, host wall incl. D2H); device %.1f ms = coarse MLP %.1f + fine MLP %.1f + other %.1f; "
-           "%.1f%% of the %s MFMA roofline\n",
+           "%s%.1f%% of the %s MFMA roofline%s\n",
            arch, n_cus, (double)st.n_rays / best, frames, st.ms_total, st.ms_coarse_mlp, st.ms_fine_mlp, st.ms_other,
+           skips ? "the ALGORITHMIC work of these rays per second = " : "",
            100.0 * mfma_flops * (double)st.n_rays * flop_ray / (st.ms_total * 1e-3) / (gpus * (bf16 ? 2500e12 : 157.3e12)),
-           bf16 ? "2.5 PFLOP/s bf16" : "157.3 TFLOP/s fp32");
+           bf16 ? "2.5 PFLOP/s bf16" : "157.3 TFLOP/s fp32", skips ? " (work provably without effect is skipped: not a utilisation figure)" : "");
     if (opts.certify_zero) // the audit of the last frame (first context): what the certificates rested on
         printf("certify_zero audit: %llu certificates evaluated all the same, %llu violations, margins %.3g / %.3g, least headroom %.3g / %.3g, largest bf16 error %.3g / %.3g, "
                "frame rendered again %u time(s), %u rays beyond their predicted cut\n", (unsigned long long)st.n_certify_audited, (unsigned long long)st.n_certify_violations,
