@@ -2,7 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
-enum { MLP_MODE_POINTS = 0, MLP_MODE_RAYS = 1, MLP_MODE_LIST = 2 }; // LIST (f32 kernel only): ray mode over a device-side list of sample indices
+enum { MLP_MODE_POINTS = 0, MLP_MODE_RAYS = 1, MLP_MODE_LIST = 2 }; // LIST (f32 and split kernels): ray mode over a device-side list of sample indices (bit 31 of an entry: audited certificate)
 
 struct MlpArgs {
     const float *wstream;      // packed weight stream (mlp_layout.h), device
@@ -24,7 +24,7 @@ struct MlpArgs {
     unsigned long long *skip_counter; // optional: number of skipped 128-point tiles (atomic)
     unsigned long long *clock_out; // optional diagnostic: per workgroup {shader cycles, 100 MHz ticks} of the tile loop
     unsigned int *nonfinite;       // optional (split arithmetics): += points whose density pre-activation is NaN / inf (f16 range overflow)
-    // zero certification (experimental, nerf_api.cpp): the bf16 kernel stores the density PRE-activation (no ReLU) in sigma_out ...
+    // zero certification (nerf_render_opts.certify_zero; nerf_api.cpp cert_pass): the bf16 kernel stores the density PRE-activation (no ReLU) in sigma_out ...
     int raw_pre;
     // ... and the f32 kernel evaluates only the listed samples (MLP_MODE_LIST: slot i -> sample point_list[i] = ray * samples_per_ray + k;
     // outputs are scattered to the sample's own position; n_points = capacity of the list, *point_list_count = its length)
