@@ -62,6 +62,14 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 #ifndef NERF_BV2_AHEAD
 #define NERF_BV2_AHEAD 4
 #endif
+#ifndef NERF_BV2_HALF_SYNC
+#define NERF_BV2_HALF_SYNC 0 // 1 (needs NERF_BV2_RING_SLOTS=5): one vmcnt + s_barrier per TWO chunks.  Three chunks are pre-loaded, chunk k + 3 is DMA'd
+#endif                       // during chunk k into the slot of chunk k - 2; the barrier in the middle of every even chunk c proves chunks <= c + 2 landed
+                             // (all issued before it) and every wave past chunk c - 1.  Round-4 experiment (profiles/r04_bf16_half_sync_ab.log):
+                             // same results, sigma-only kernel 26.1 ms against 26.0 -- the barrier is not what costs -- and the full kernel slower.
+#if NERF_BV2_HALF_SYNC
+static_assert(NERF_BV2_RING_SLOTS == 5, "NERF_BV2_HALF_SYNC needs a five-slot ring");
+#endif
 // timing-only diagnostics (results are garbage): which resource bounds the kernel
 #ifndef NERF_BV2_DIAG_NO_DMA
 #define NERF_BV2_DIAG_NO_DMA 0
@@ -97,6 +105,7 @@ struct PipeV {
     uint32_t ring_addr, wr_slot_off, next_off, stream_bytes;
     const char *gbase, *cur_src;
     uint32_t cur_dst, lane16;
+    uint32_t sync_phase;          // NERF_BV2_HALF_SYNC: 0 = this chunk's middle carries the barrier
 };
 
 __device__ __forceinline__ void pipe_next_chunk(PipeV &P) {
@@ -115,8 +124,9 @@ __device__ __forceinline__ void pipe_next_chunk(PipeV &P) {
 __device__ __forceinline__ void pipe_start(PipeV &P) {
     P.next_off = 0;
     P.wr_slot_off = 0;
+    P.sync_phase = 0;
 #pragma unroll
-    for (int c = 0; c < kRS - 1; ++c) {
+    for (int c = 0; c < (NERF_BV2_HALF_SYNC ? 3 : kRS - 1); ++c) {
         pipe_next_chunk(P);
 #pragma unroll
         for (int i = 0; i < 4; ++i) glds_piece(P.lane16, P.cur_src + i * 1024, P.cur_dst + i * 1024);
@@ -136,7 +146,10 @@ __device__ __forceinline__ bf16x8 pipe_take(PipeV &P) {
     if constexpr (PH == 8) {
         // chunk c + 1 was issued kRS - 2 chunks ago; the 4 (kRS - 3) pieces of the chunks issued since may still be in
         // flight (VMEM returns in order; any compiler-issued access in between only makes this wait longer, never shorter)
-#if NERF_BV2_DIAG_NO_BARRIER
+#if NERF_BV2_HALF_SYNC
+        if (P.sync_phase == 0) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory"); // wave-uniform; every wave has consumed the same number of chunks
+        P.sync_phase ^= 1u;
+#elif NERF_BV2_DIAG_NO_BARRIER
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (kRS - 3)) : "memory");
 #else
         asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(4 * (kRS - 3)) : "memory");
