@@ -476,7 +476,7 @@ int render_once(nerf_ctx *c, const nerf_camera *cam, const nerf_render_opts *o, 
         if ((rc = ensure_bytes(c, (void **)&c->d_point_list, &c->point_list_bytes, cert_cap * sizeof(unsigned int)))) return rc;
         cert_cap = std::min<size_t>(pass_samples, c->point_list_bytes / sizeof(unsigned int)); // an earlier, larger allocation is kept
         if ((rc = ensure_bytes(c, (void **)&c->d_jstar, &c->jstar_bytes, rows_per_pass * RW * sizeof(int)))) return rc;
-        aux_cap = 2 * (pass_samples / ((size_t)c->cert_audit_mask + 1)) + 4096; // twice the expected number of audited certificates: one that does not fit is not audited
+        aux_cap = 2 * (pass_samples / ((size_t)std::min(c->cert_audit_mask, c->cert_audit_mask_near) + 1)) + 4096; // more than the audit can select: a certificate that does not fit is not audited
         if ((rc = ensure_bytes(c, (void **)&c->d_cert_aux, &c->cert_aux_bytes, aux_cap * 2 * sizeof(unsigned int)))) return rc;
         if ((rc = ensure_bytes(c, (void **)&c->d_cert, &c->cert_bytes, kCertSlots * 2 * n_pass * sizeof(unsigned int)))) return rc;
         HIP_TRY(c, hipMemsetAsync(c->d_cert, 0, kCertSlots * 2 * n_pass * sizeof(unsigned int), st));
@@ -572,7 +572,7 @@ int render_once(nerf_ctx *c, const nerf_camera *cam, const nerf_render_opts *o, 
                 CertPlanArgs p{};
                 p.pre = sigma_out; p.t = t_in; p.n_rays = n_rays; p.spr = spr; p.far_ = cam->far_;
                 p.margin = c->cert_margin[which]; p.depth_limit = c->cert_depth_limit;
-                p.audit_mask = c->cert_audit_mask; p.audit_salt = (unsigned)(o->seed * 0x9E3779B97F4A7C15ull >> 32) + 0x632BE5ABu * passes + (unsigned)which;
+                p.audit_mask = c->cert_audit_mask; p.audit_mask_near = c->cert_audit_mask_near; p.audit_salt = (unsigned)(o->seed * 0x9E3779B97F4A7C15ull >> 32) + 0x632BE5ABu * passes + (unsigned)which;
                 p.list = c->d_point_list; p.count = slots; p.capacity = cap; p.jstar = c->d_jstar;
                 // full evaluations: probable zeros (bf16 pre-activation below -margin / 3: three times the largest bf16 error the lego audits see
                 // is not needed for a skip -- a positive density among them only keeps its tile's colour heads) and the audited certificates go
@@ -897,6 +897,7 @@ int nerf_create(int device_id, nerf_ctx **out) try {
     if (const char *env = getenv("NERF_CERTIFY_ZERO_FRAC")) { const double v = atof(env); if (v > 0.0 && v <= 1.0) c->cert_zero_frac = (float)v; }
     if (const char *env = getenv("NERF_CERTIFY_CUT_DEPTH")) { const double v = atof(env); if (v > 0.0) c->cert_depth_limit = (float)v; }
     if (const char *env = getenv("NERF_CERTIFY_AUDIT_MASK")) { const long v = atol(env); if (v >= 0 && ((v + 1) & v) == 0) c->cert_audit_mask = (unsigned)v; }
+    if (const char *env = getenv("NERF_CERTIFY_AUDIT_MASK_NEAR")) { const long v = atol(env); if (v >= 0 && ((v + 1) & v) == 0) c->cert_audit_mask_near = (unsigned)v; }
     if (const char *env = getenv("NERF_CERTIFY_MARGINS")) {
         float m0 = 0.f, m1 = 0.f;
         if (sscanf(env, "%f,%f", &m0, &m1) == 2 && m0 > 0.f && m1 > 0.f) { c->cert_margin_floor[0] = m0; c->cert_margin_floor[1] = m1; c->cert_margin[0] = m0; c->cert_margin[1] = m1; }

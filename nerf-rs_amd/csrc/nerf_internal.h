@@ -67,7 +67,9 @@ struct nerf_ctx {
     float cert_margin_floor[2] = {nerfint::kCertMarginCoarse, nerfint::kCertMarginFine};
     float cert_depth_limit = 9.6f;        // predicted cut: bf16 optical depth > 9.6 (the exact cut is at T < 1e-4 = depth 9.21; nothing but work depends on it:
                                           // lego frame 0 rays fall back at 9.5, 25 at 9.35, 1132 of 640 000 at 9.25 -- tools/sweep_certify.py)
-    unsigned cert_audit_mask = 63;        // one certified sample in 64 is audited
+    unsigned cert_audit_mask = 127;       // one certified sample in 128 is audited ...
+    unsigned cert_audit_mask_near = 15;   // ... and one in 16 of those certified by less than twice the margin: the same number of audits as a flat 1 in 64
+                                          // on the lego frame, four times as many where a certificate is at risk
     bool cert_zero_tiles = true;          // probable zeros + audited certificates in the list's back part, evaluated with skip_empty
     float cert_zero_frac = 0.1f;          // "probably zero": bf16 pre-activation below -margin x this (C3 frame: 1/2 -> 334.6 ms, 1/3 -> 333.1, 0.1 -> 330.5, 0.02 -> 331.0: tools/sweep_certify_zero_frac.py)
     bool cert_seq_prefilter = true;       // bf16 pre-filter ray-sequential with its own predicted cut (false: the fused bf16 kernel over all samples)

@@ -72,7 +72,8 @@ struct CertPlanArgs {
     float far_;
     float margin;        // a sample is certified (density 0) iff pre < -margin
     float depth_limit;   // predicted cut: the first sample with bf16 optical depth in front of it > depth_limit
-    unsigned audit_mask; // 2^k - 1: one certified sample in 2^k is audited
+    unsigned audit_mask; // 2^k - 1: one certified sample in 2^k is audited ...
+    unsigned audit_mask_near; // ... and one in 2^j of those certified by less than twice the margin (pre > -2 margin)
     unsigned audit_salt;
     unsigned *list;      // phase-1 list: sample index | (audit ? 1 << 31 : 0)
     unsigned *count;     // += entries (also those beyond capacity)

@@ -402,7 +402,7 @@ __global__ void k_box_downsample(const float *__restrict__ rays, float *__restri
 // summation order) and finds j* = the first sample whose bf16 transmittance exp(-depth) is below the prediction threshold (depth_limit =
 // -ln of it; kept well below the exact cut's 1e-4 so that the exact cut almost always falls inside [0, j*)).  Then
 //   * samples [0, j*): the UNCERTAIN ones (not certified: positive, near zero, NaN) go on the phase-1 list; of the certified ones a
-//     deterministic 1 / (audit_mask + 1) goes on the list too, with bit 31 set: the exact kernel evaluates them like any other listed
+//     deterministic 1 / (audit_mask_near + 1) of those certified by less than twice the margin and 1 / (audit_mask + 1) of the rest go on the list too, with bit 31 set: the exact kernel evaluates them like any other listed
 //     sample but stores the raw pre-activation, which k_cert_audit compares with 0 and with the bf16 value (remembered in `aux`);
 //   * samples [j*, spr): uncertain ones are only MARKED (kCertMarker in the buffer); k_cert_verify either clears the marks (the exact
 //     transmittance over [0, j*) did fall below 1e-4: the ray is decided) or lists them for a second exact launch (rare);
@@ -419,7 +419,7 @@ __device__ __forceinline__ bool cert_audit_pick(unsigned idx, unsigned salt, uns
 }
 
 // dynamic LDS: 4 waves x (rays_per_wave x spr entries + kAuxStage {stage position, bf16 pre-activation} pairs)
-constexpr int kAuxStage = 96; // audited certificates a wave can stage between two flushes (expected: rays_per_wave x spr / 64); beyond: not audited
+constexpr int kAuxStage = 256; // audited certificates a wave can stage between two flushes (at most rays_per_wave x spr / 16 = 96 for 8 rays of 192 samples); beyond: not audited
 __global__ __launch_bounds__(256) void k_cert_plan(CertPlanArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned lds_u[];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -466,7 +466,9 @@ __global__ __launch_bounds__(256) void k_cert_plan(CertPlanArgs a) {
                 dead = i >= jstar;
                 carry += __shfl(v, 63, 64);
             }
-            bool audit = in && !dead && !unc && cert_audit_pick((unsigned)(base + i), a.audit_salt, a.audit_mask);
+            // denser where a certificate is at risk: 1 / (audit_mask_near + 1) of the samples certified by less than twice the margin,
+            // 1 / (audit_mask + 1) of the others (whose bf16 error still feeds the any-depth error statistic)
+            bool audit = in && !dead && !unc && cert_audit_pick((unsigned)(base + i), a.audit_salt, pre > -2.0f * a.margin ? a.audit_mask_near : a.audit_mask);
             const unsigned long long am = __ballot(audit);
             const unsigned aux_at = n_aux + (unsigned)__popcll(am & ((1ull << lane) - 1ull));
             audit = audit && aux_at < (unsigned)kAuxStage; // no room to remember its bf16 value: certified without audit, like its 63 siblings

@@ -32,7 +32,8 @@ def test_c3_whole_frame_is_the_f32_frame(renderer, native, samples):
     assert 0.05 < fc < 0.45 and 0.08 < ff < 0.3 and 0.6 * st.n_exec_fine_trunk < st.n_exec_colour < st.n_exec_fine_trunk   # probable zeros and audited certificates skip the colour head tile-wise
     assert st.n_certify_retries == 0 and st.n_certify_violations == 0 and st.certify_margin == (1.0, 3.0)
     certified = st.n_coarse_points + st.n_fine_points - st.n_exec_coarse_trunk - st.n_exec_fine_trunk
-    assert 0.5 * certified / 64 < st.n_certify_audited < 1.5 * certified / 64 + 1000   # audited certificates in front of the predicted cuts (most certified samples)
+    # audited: 1 in 16 of the samples certified by less than twice the margin, 1 in 128 of the others (in front of the predicted cuts)
+    assert certified / 128 * 0.9 < st.n_certify_audited < certified / 16
     assert all(h >= 0.5 * m for h, m in zip(st.certify_headroom, st.certify_margin))
     assert st.n_certify_fallback_rays < 0.01 * st.n_rays
 
@@ -142,7 +143,8 @@ def test_hot_network_widens_its_margins_instead_of_differing(native, samples, tm
         assert st.n_certify_retries >= 1 and max(st.certify_margin) > 3.0
         assert all(h >= 0.5 * m for h, m in zip(st.certify_headroom, st.certify_margin))
         img2, st2 = native.render_image(r.coarse, r.fine, cam, 128, seed=4, crop=crop, certify_zero=True, return_stats=True)
-        assert st2.certify_margin == st.certify_margin and st2.n_certify_violations == 0
+        # the next frame starts from the widened margins (another seed's audit may widen them further, never back)
+        assert all(b >= a for a, b in zip(st.certify_margin, st2.certify_margin)) and st2.n_certify_retries <= 2
         assert np.array_equal(img2, native.render_image(r.coarse, r.fine, cam, 128, seed=4, crop=crop))
         _load(native, r, SCENE)  # loading a network resets its margin
         _, st3 = native.render_image(r.coarse, r.fine, cam, 128, seed=4, crop=crop, certify_zero=True, return_stats=True)
