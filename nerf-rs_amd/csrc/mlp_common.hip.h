@@ -28,6 +28,23 @@ __device__ __forceinline__ void glds_piece(uint32_t lane16, const char *gsrc, ui
                  : "memory");
 }
 
+// The same with M0 -- the LDS destination -- written once per chunk quarter (dma_set_dst, where the chunk is selected) and the quarter's
+// four pieces addressed by the instruction offset, which advances the global AND the LDS address.  Beside MFMAs a piece costs its wave 25
+// cycles with M0 saved / written / restored around it, 17 with M0 written, 0 with M0 left alone (tools/probes/lds_dma_stagger_probe.hip).
+// hipcc uses M0 for nothing of its own in these kernels (no LDS-direct, no s_movrel, no sendmsg): tests/test_host_logic.py checks the ISA.
+#ifndef NERF_M0_PER_CHUNK
+#define NERF_M0_PER_CHUNK 1
+#endif
+__device__ __forceinline__ void dma_set_dst(uint32_t dst) { asm volatile("s_mov_b32 m0, %0\n\ts_nop 0" ::"s"(dst) : "memory"); }
+__device__ __forceinline__ void glds_piece_m0(uint32_t lane16, const char *gsrc, int i) {
+    switch (i) { // i is a constant after unrolling
+    case 0:  asm volatile("global_load_lds_dwordx4 %0, %1" ::"v"(lane16), "s"(gsrc) : "memory"); break;
+    case 1:  asm volatile("global_load_lds_dwordx4 %0, %1 offset:1024" ::"v"(lane16), "s"(gsrc) : "memory"); break;
+    case 2:  asm volatile("global_load_lds_dwordx4 %0, %1 offset:2048" ::"v"(lane16), "s"(gsrc) : "memory"); break;
+    default: asm volatile("global_load_lds_dwordx4 %0, %1 offset:3072" ::"v"(lane16), "s"(gsrc) : "memory"); break;
+    }
+}
+
 // ReLU as a signed-integer max on the bit pattern: one v_max_i32 (fmaxf costs an extra canonicalising v_max), and --
 // unlike inline asm -- visible to hipcc's hazard recogniser, which must pad the VALU-write -> MFMA-operand-read
 // wait states.  Negative floats and -0.0 are negative integers -> +0.0; positives are unchanged.

@@ -80,10 +80,15 @@ __device__ __forceinline__ void pipe_next_chunk(Pipe &P) {
     P.next_off = (off == P.stream_bytes) ? 0u : off;
     slot += kChunkBytes;
     P.wr_slot_off = (slot == kRingSlots * kChunkBytes) ? 0u : slot;
+#if NERF_M0_PER_CHUNK
+    dma_set_dst(P.cur_dst);
+#endif
 }
 
 __device__ __forceinline__ void pipe_issue_piece(Pipe &P, int i) {
-#if !NERF_DIAG_NO_DMA
+#if !NERF_DIAG_NO_DMA && NERF_M0_PER_CHUNK
+    glds_piece_m0(P.lane16, P.cur_src, i);
+#elif !NERF_DIAG_NO_DMA
     glds_piece(P.lane16, P.cur_src + i * 1024, P.cur_dst + i * 1024);
 #else
     (void)P; (void)i;

@@ -53,8 +53,14 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 #define ENCODE_POINT encode_point<true>
 #define ENCODE_DIR encode_dir<true>
 #endif
+#ifndef NERF_BV2_M0_PER_CHUNK
+#define NERF_BV2_M0_PER_CHUNK 1 // M0 (the LDS destination of an LDS-DMA piece) is written ONCE per chunk, where the chunk is selected, and the four pieces
+#endif                          // of the wave's chunk quarter go out by instruction offset alone.  Round 4, tools/probes/lds_dma_stagger_probe.hip: beside MFMAs a
+                                // piece costs 25 cycles with M0 saved / written / restored around it, 17 with M0 written only, 0 with M0 left alone -- the
+                                // "price of an LDS-DMA instruction" of rounds 1-3 was the price of writing M0.  hipcc emits no M0 use of its own in these
+                                // kernels (no LDS-direct, no s_movrel, no sendmsg; tests/test_host_logic.py checks the generated ISA).
 #ifndef NERF_BV2_M0_NOSAVE
-#define NERF_BV2_M0_NOSAVE 0 // 1: drop the M0 save/restore around each LDS-DMA piece (+0.3 %; relies on hipcc not using M0)
+#define NERF_BV2_M0_NOSAVE 0 // (NERF_BV2_M0_PER_CHUNK=0 only) 1: drop the M0 save/restore around each LDS-DMA piece (+0.3 %)
 #endif
 #ifndef NERF_BV2_PAIR_READS
 #define NERF_BV2_PAIR_READS 1 // A operands fetched two pieces at a time, one s_waitcnt per pair
@@ -117,6 +123,22 @@ __device__ __forceinline__ void pipe_next_chunk(PipeV &P) {
     P.next_off = (off == P.stream_bytes) ? 0u : off;
     slot += kCB;
     P.wr_slot_off = (slot == kRS * kCB) ? 0u : slot;
+#if NERF_BV2_M0_PER_CHUNK
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0" ::"s"(P.cur_dst) : "memory"); // the chunk quarter's LDS destination; its pieces add their instruction offset
+#endif
+}
+
+// piece at byte offset `off` of the chunk quarter pipe_next_chunk selected (pipe_start's bursts)
+__device__ __forceinline__ void glds_piece_at(uint32_t lane16, const char *gsrc, uint32_t dst, int off) {
+#if NERF_BV2_M0_PER_CHUNK
+    (void)dst;
+    if (off == 0)         asm volatile("global_load_lds_dwordx4 %0, %1" ::"v"(lane16), "s"(gsrc) : "memory");
+    else if (off == 1024) asm volatile("global_load_lds_dwordx4 %0, %1 offset:1024" ::"v"(lane16), "s"(gsrc) : "memory");
+    else if (off == 2048) asm volatile("global_load_lds_dwordx4 %0, %1 offset:2048" ::"v"(lane16), "s"(gsrc) : "memory");
+    else                  asm volatile("global_load_lds_dwordx4 %0, %1 offset:3072" ::"v"(lane16), "s"(gsrc) : "memory");
+#else
+    glds_piece(lane16, gsrc + off, dst + off);
+#endif
 }
 
 // (Re)start at chunk 0: chunks 0 .. kRS - 2 loaded and visible, the first kAhead A operands prefetched.  The caller guarantees
@@ -129,7 +151,7 @@ __device__ __forceinline__ void pipe_start(PipeV &P) {
     for (int c = 0; c < (NERF_BV2_HALF_SYNC ? 3 : kRS - 1); ++c) {
         pipe_next_chunk(P);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) glds_piece(P.lane16, P.cur_src + i * 1024, P.cur_dst + i * 1024);
+        for (int i = 0; i < 4; ++i) glds_piece_at(P.lane16, P.cur_src, P.cur_dst, i * 1024);
     }
     asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
     P.rd_slot_off = 0;
@@ -194,7 +216,10 @@ __device__ __forceinline__ bf16x8 pipe_take(PipeV &P) {
 // pieces of a wave's chunk quarter share one scalar base pair and one M0 value.
 template <int OFF>
 __device__ __forceinline__ void glds_piece_off(uint32_t lane16, const char *gsrc, uint32_t dst) {
-#if NERF_BV2_DMA_INST_OFFSET && NERF_BV2_M0_NOSAVE
+#if NERF_BV2_M0_PER_CHUNK
+    (void)dst; // M0 holds it since pipe_next_chunk
+    asm volatile("global_load_lds_dwordx4 %0, %1 offset:%2" : : "v"(lane16), "s"(gsrc), "n"(OFF) : "memory");
+#elif NERF_BV2_DMA_INST_OFFSET && NERF_BV2_M0_NOSAVE
     // M0 is written and read inside this one statement and not restored: hipcc emits no M0 use of its own in this kernel
     // (no LDS-direct, no s_movrel, no sendmsg; checked on the generated ISA: every m0 reference is one of these statements)
     asm volatile("s_mov_b32 m0, %2\n\t"

@@ -96,6 +96,9 @@ __device__ __forceinline__ void pipe_next_chunk(PipeV &P) {
     P.next_off = (off == P.stream_bytes) ? 0u : off;
     slot += kCB;
     P.wr_slot_off = (slot == kRS * kCB) ? 0u : slot;
+#if NERF_M0_PER_CHUNK
+    dma_set_dst(P.cur_dst);
+#endif
 }
 
 __device__ __forceinline__ void pipe_start(PipeV &P) {
@@ -105,7 +108,13 @@ __device__ __forceinline__ void pipe_start(PipeV &P) {
     for (int c = 0; c < kRS - 1; ++c) {
         pipe_next_chunk(P);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) glds_piece(P.lane16, P.cur_src + i * 1024, P.cur_dst + i * 1024);
+        for (int i = 0; i < 4; ++i) {
+#if NERF_M0_PER_CHUNK
+            glds_piece_m0(P.lane16, P.cur_src, i);
+#else
+            glds_piece(P.lane16, P.cur_src + i * 1024, P.cur_dst + i * 1024);
+#endif
+        }
     }
     asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
     P.rd_slot_off = 0;
@@ -149,6 +158,11 @@ __device__ __forceinline__ bf16x8 pipe_take(PipeV &P) {
 
 template <int OFF>
 __device__ __forceinline__ void glds_piece_off(uint32_t lane16, const char *gsrc, uint32_t dst) {
+#if NERF_M0_PER_CHUNK
+    (void)dst; // M0 holds it since pipe_next_chunk
+    asm volatile("global_load_lds_dwordx4 %0, %1 offset:%2" : : "v"(lane16), "s"(gsrc), "n"(OFF) : "memory");
+    return;
+#endif
     uint32_t keep;
     asm volatile("s_mov_b32 %0, m0\n\t"
                  "s_mov_b32 m0, %3\n\t"

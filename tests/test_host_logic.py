@@ -582,3 +582,45 @@ def test_one_file_variant_script_tags_its_library():
     """tools/variant_one.sh (one kernel file rebuilt with tuning switches) must tag its library like `make variant` does: until round 4 it did not."""
     src = open(os.path.join(ROOT, "tools", "variant_one.sh")).read()
     assert "-DNERF_BUILD_VARIANT=" in src and "nerf_host_api.cpp" in src and "amdgpu-mfma-vgpr-form=1" in src
+
+
+def test_m0_belongs_to_the_lds_dma_statements(native, tmp_path):
+    """The f32 and bf16 MLP kernels write M0 -- the LDS destination of their LDS-DMA pieces -- once per chunk quarter and leave it alone until
+    the next chunk (mlp_common.hip.h dma_set_dst / glds_piece_m0), which is only right if hipcc uses M0 for nothing of its own.  Checked on
+    the ISA of the library as built: every instruction that names m0 is one of the kernels' own s_mov_b32, no instruction with an implicit
+    M0 operand exists, and where M0 is never read back (the per-chunk kernels) four pieces follow every write."""
+    bundler, objdump, objcopy = (f"/opt/rocm/lib/llvm/bin/{t}" for t in ("clang-offload-bundler", "llvm-objdump", "llvm-objcopy"))
+    if not all(os.path.exists(t) for t in (bundler, objdump, objcopy)):
+        pytest.skip("ROCm llvm tools not installed")
+    import subprocess
+    fat = tmp_path / "fat.bin"
+    subprocess.run([objcopy, "--dump-section", f".hip_fatbin={fat}", native.lib_path(), str(tmp_path / "ignored.so")], check=True)
+    data = fat.read_bytes()
+    starts = [m.start() for m in re.finditer(b"__CLANG_OFFLOAD_BUNDLE__", data)]
+    assert len(starts) >= 5  # one bundle per kernel file
+    per_chunk_kernels = 0
+    for i, s in enumerate(starts):
+        e = starts[i + 1] if i + 1 < len(starts) else len(data)
+        b, co = tmp_path / f"b{i}.bin", tmp_path / f"b{i}.co"
+        b.write_bytes(data[s:e])
+        subprocess.run([bundler, "--unbundle", "--type=o", f"--input={b}", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--output={co}"], check=True)
+        isa = subprocess.run([objdump, "-d", str(co)], check=True, capture_output=True, text=True).stdout
+        writes = reads = pieces = 0
+        for line in isa.splitlines():
+            ins = line.split("//")[0].strip()
+            assert not re.match(r"(s_movrel|v_movrel|s_sendmsg|ds_gws|s_set_gpr_idx|v_interp|ds_\w*addtid|\w+ .*lds_direct)", ins), ins
+            if "global_load_lds_dwordx4" in ins:
+                pieces += 1
+            if re.search(r"\bm0\b", ins):
+                if re.fullmatch(r"s_mov_b32 m0, s\d+", ins):
+                    writes += 1
+                elif re.fullmatch(r"s_mov_b32 s\d+, m0", ins):
+                    reads += 1
+                else:
+                    raise AssertionError(f"an instruction of hipcc's own touches m0: {ins}")
+        if writes and not reads:  # M0 per chunk quarter
+            assert pieces == 4 * writes, (i, pieces, writes)
+            per_chunk_kernels += 1
+        elif writes:              # saved, written, restored around every piece (the split arithmetics)
+            assert writes == 2 * reads and pieces == reads, (i, pieces, writes, reads)
+    assert per_chunk_kernels >= 3  # mlp_kernel, mlp_kernel_seq, mlp_kernel_bf16v2
