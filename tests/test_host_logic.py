@@ -624,3 +624,24 @@ def test_m0_belongs_to_the_lds_dma_statements(native, tmp_path):
         elif writes:              # saved, written, restored around every piece (the split arithmetics)
             assert writes == 2 * reads and pieces == reads, (i, pieces, writes, reads)
     assert per_chunk_kernels >= 3  # mlp_kernel, mlp_kernel_seq, mlp_kernel_bf16v2
+
+
+def test_header_is_plain_c_and_links(native, tmp_path):
+    """The boundary is a C ABI: include/nerf_mi355x.h must compile as strict C99 (what a cgo / Rust bindgen / plain C host sees) and a C
+    program must link against the library and call its host-only entry points (no GPU needed for these)."""
+    if not shutil.which("gcc"):
+        pytest.skip("gcc not installed")
+    import subprocess
+    src = tmp_path / "host.c"
+    src.write_text('#include <stdio.h>\n#include "nerf_mi355x.h"\n'
+                   'int main(void) {\n'
+                   '    nerf_render_opts o; nerf_camera cam; nerf_stats st;\n'
+                   '    (void)o; (void)cam; (void)st;\n'
+                   '    printf("%d %s\\n", (int)nerf_abi_version(), nerf_build_variant());\n'
+                   '    return 0;\n}\n')
+    exe = tmp_path / "host"
+    libdir = os.path.dirname(native.lib_path())
+    subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", f"-I{os.path.join(ROOT, 'include')}", str(src), "-o", str(exe),
+                    f"-L{libdir}", "-lnerf_mi355x", f"-Wl,-rpath,{libdir}"], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()
+    assert int(out[0]) == native.abi_version() if hasattr(native, "abi_version") else int(out[0]) >= 5
