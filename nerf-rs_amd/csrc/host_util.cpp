@@ -256,6 +256,21 @@ void split_f16x2(float v, uint16_t out[2]) {
 }
 
 // f16x2 stream: every piece of the v1 order followed by the piece of the second part of the same weights
+// The f16 twin of bf16_stream_from_v1order (mlp_kernel_f16v2.hip: certify_zero's pre-filter): every weight rounded to f16 (RNE).  Returns false
+// if a weight is outside the f16 range (the pre-filter then stays bf16 for that network).
+bool f16_stream_from_v1order(const std::vector<float> &v1f, std::vector<uint16_t> &ws) {
+    ws.resize(v1f.size());
+    bool in_range = true;
+    for (size_t i = 0; i < v1f.size(); ++i) {
+        const float v = v1f[i];
+        if (!(fabsf(v) <= 65504.0f)) in_range = false;
+        const _Float16 h = (_Float16)v;
+        memcpy(&ws[i], &h, sizeof(uint16_t));
+    }
+    ws.resize((size_t)kChunksFullBf16 * kChunkBytesBf16 / 2, (uint16_t)0); // pad viewdirs to whole chunks
+    return in_range;
+}
+
 bool x2_stream_from_v1order(const std::vector<float> &v1f, std::vector<uint16_t> &ws) {
     const size_t n_pieces = v1f.size() / 512;
     ws.assign(n_pieces * 2 * 512, (uint16_t)0);

@@ -44,6 +44,7 @@ void x3_stream_from_v1order(const std::vector<float> &v1f, std::vector<uint16_t>
 // f32 by two-way f16 split (mlp_kernel_f16x2.hip): w = w1 + w2, two pieces per v1 piece; false if a weight exceeds the f16 range
 void split_f16x2(float v, uint16_t out[2]);
 bool x2_stream_from_v1order(const std::vector<float> &v1f, std::vector<uint16_t> &wstream);
+bool f16_stream_from_v1order(const std::vector<float> &v1f, std::vector<uint16_t> &wstream); // one f16 per weight, bf16_stream_from_v1order's order
 
 // camera_from_samples (src/lib.rs:614-645)
 void camera_from_values(float near_, float far_, const float origin[3], const float forward[3], const float up[3],

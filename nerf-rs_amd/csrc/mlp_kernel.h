@@ -43,6 +43,9 @@ hipError_t nerf_mlp_launch(const MlpArgs &a, bool full, int n_blocks, hipStream_
 // bf16-operand variant (mlp_kernel_bf16v2.hip): a.wstream is the output-tile-major stream (mlp_layout.h kChunks*Bf16V2)
 hipError_t nerf_mlp_bf16v2_init();
 hipError_t nerf_mlp_bf16v2_launch(const MlpArgs &a, bool full, int n_blocks, hipStream_t stream);
+// mlp_kernel_f16v2.hip: the f16 twin of the bf16 kernel, sigma-only forms (certify_zero's pre-filter; MlpArgs / SeqArgs .nonfinite += tiles that left the f16 range)
+hipError_t nerf_prefilter_f16v2_init();
+hipError_t nerf_mlp_f16v2_launch(const MlpArgs &a, int n_blocks, hipStream_t stream);
 // skip_dead in the bf16 arithmetic (same file): two ray cursors per wave; the trunk exports the bf16-packed relu(h8) of the live samples
 // (512 B per sample; capacity nerf_seq_h8_bytes_bf16) for nerf_colour_bf16_launch.  SeqArgs / ColourArgs are declared below.
 struct SeqArgs;
@@ -50,6 +53,7 @@ struct ColourArgs;
 hipError_t nerf_seq_bf16_init();
 size_t nerf_seq_h8_bytes_bf16(size_t n_samples);
 hipError_t nerf_trunk_seq_bf16_launch(const SeqArgs &a, bool export_live, int n_blocks, hipStream_t stream);
+hipError_t nerf_trunk_seq_f16v2_launch(const SeqArgs &a, int n_blocks, hipStream_t stream); // SeqArgs.prefilter only
 hipError_t nerf_colour_bf16_launch(const ColourArgs &a, int n_blocks, hipStream_t stream);
 // the same arithmetic on v_mfma_f32_16x16x32_bf16 (mlp_kernel_bf16v3.hip): its own piece contents, the same chunk counts
 hipError_t nerf_mlp_bf16v3_init();

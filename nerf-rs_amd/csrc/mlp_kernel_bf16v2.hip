@@ -29,8 +29,22 @@
 using namespace nerfmlp;
 using namespace mlpdev;
 
+// NERF_V2_F16 = 1 (mlp_kernel_f16v2.hip includes this file with it): the same kernels on f16 operands -- v_mfma_f32_32x32x16_f16, the same fragment
+// layouts, the same stream order with f16-rounded weights.  Only the sigma-only forms are built: certify_zero's pre-filter, where f16's
+// 11 significand bits make the pre-activation 8 x closer to the exact one than bf16's 8 (so far fewer samples need the exact kernel).  f16 overflows
+// at 65 504: an overflow ends in a non-finite density pre-activation (range_left below), which counts in *nonfinite -- the host then goes back to bf16.
+#ifndef NERF_V2_F16
+#define NERF_V2_F16 0
+#endif
+#if NERF_V2_F16
+typedef _Float16 bf16x8 __attribute__((ext_vector_type(8))); // (the names stay: "the 16-bit operand type of this build")
+typedef _Float16 bf16x2 __attribute__((ext_vector_type(2)));
+#define V2SYM(bf16_name, f16_name) f16_name
+#else
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+#define V2SYM(bf16_name, f16_name) bf16_name
+#endif
 typedef short s16x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
@@ -251,7 +265,11 @@ __device__ __forceinline__ void pipe_dma(PipeV &P) {
     if constexpr (PH >= 9 && (PH & 1) == 1) glds_piece_off<((PH - 9) / 2) * 1024>(P.lane16, P.cur_src, P.cur_dst);
 }
 
+#if NERF_V2_F16
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
+#else
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
+#endif
 
 // two f32 -> one packed bf16 pair (RNE); ReLU as a packed signed-16-bit max (a negative bf16 is a negative int16)
 template <bool RELU>
@@ -307,6 +325,19 @@ __device__ __forceinline__ void convert_half(const f32x16 &acc, u32x4 &na, u32x4
         if constexpr (PR < 4) na[PR] = c;
         else                  nb[PR - 4] = c;
     }
+}
+
+// NERF_V2_F16: did the f16 range (65 504) not hold for one of this wave's points?  An activation beyond it is packed as +inf; every pre-activation of the
+// next layer is then +-inf or NaN (inf x w, inf - inf), +inf and NaN survive the ReLU (a signed-integer max), and so on down to the density
+// pre-activation, which comes out non-finite -- unless all 256 features of some layer turned -inf / negative NaN at once.  So nothing is watched in
+// the hot loop: a non-finite density pre-activation marks the tile (and is never certified: k_cert_plan treats it as uncertain).  (wave-uniform)
+__device__ __forceinline__ bool range_left(float pre0, float pre1) {
+#if NERF_V2_F16
+    return __any(!(fabsf(pre0) <= 3.0e38f) || !(fabsf(pre1) <= 3.0e38f));
+#else
+    (void)pre0; (void)pre1;
+    return false;
+#endif
 }
 
 // this lane-half's 16 bias values of output tile nt ([nt][h][16] in LDS)
@@ -470,7 +501,7 @@ __device__ __forceinline__ void colour_layers(u32x4 (&X0)[16], u32x4 (&X1)[16], 
 } // namespace
 
 template <bool FULL, int MODE>
-__global__ __launch_bounds__(256, 1) void nerf_mlp_kernel_bf16v2(const MlpArgs A) {
+__global__ __launch_bounds__(256, 1) void V2SYM(nerf_mlp_kernel_bf16v2, nerf_mlp_kernel_f16v2)(const MlpArgs A) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const LDS_AS char *lds = (const LDS_AS char *)smem;
     const LDS_AS float *small = (const LDS_AS float *)(lds + kRS * kCB);
@@ -546,6 +577,7 @@ __global__ __launch_bounds__(256, 1) void nerf_mlp_kernel_bf16v2(const MlpArgs A
 
         trunk_layers<FULL>(E0, E1, X0, X1, Y0, Y1, C, small, H, P, h);
         const float pre0 = xhalf_sum(H.alpha[0]) + small[kMiscOff + 0], pre1 = xhalf_sum(H.alpha[1]) + small[kMiscOff + 0];
+        if (range_left(pre0, pre1) && A.nonfinite && lane == 0) atomicAdd(A.nonfinite, 1u); // NERF_V2_F16 only: this wave's 64 points cannot be trusted
         // raw_pre (zero certification, nerf_api.cpp): the pre-activation itself leaves the kernel -- how far below 0 it is decides
         // whether the f32 kernel needs to look at the sample at all
         const float s0 = A.raw_pre ? pre0 : fmaxf(pre0, 0.f); // ReLU(alpha) (src/network.rs:216)
@@ -652,7 +684,7 @@ __device__ __forceinline__ void chunk_finish_prefilter(mlpseq::RayWork &W, const
 }
 
 template <bool EXPORT>
-__global__ __launch_bounds__(256, 1) void nerf_trunk_seq_kernel_bf16(const SeqArgs A) {
+__global__ __launch_bounds__(256, 1) void V2SYM(nerf_trunk_seq_kernel_bf16, nerf_trunk_seq_kernel_f16v2)(const SeqArgs A) {
     using namespace mlpseq;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const LDS_AS char *lds = (const LDS_AS char *)smem;
@@ -694,6 +726,7 @@ __global__ __launch_bounds__(256, 1) void nerf_trunk_seq_kernel_bf16(const SeqAr
         for (int c = 0; c < 3; ++c) H.rgb[0][c] = H.rgb[1][c] = 0.f;
         trunk_layers<EXPORT>(E0, E1, X0, X1, Y0, Y1, C, small, H, P, h);
         const float pre0 = xhalf_sum(H.alpha[0]) + small[kMiscOff + 0], pre1 = xhalf_sum(H.alpha[1]) + small[kMiscOff + 0];
+        if (range_left(pre0, pre1) && A.nonfinite && lane == 0) atomicAdd(A.nonfinite, 1u); // NERF_V2_F16 only
         if (!EXPORT && A.prefilter) { // wave-uniform
             chunk_finish_prefilter(W0, A, c0, pre0, p, h);
             chunk_finish_prefilter(W1, A, c1, pre1, p, h);
@@ -709,6 +742,7 @@ __global__ __launch_bounds__(256, 1) void nerf_trunk_seq_kernel_bf16(const SeqAr
     work_done(W1, A, lane);
 }
 
+#if !NERF_V2_F16 // the f16 build holds the sigma-only forms only
 __global__ __launch_bounds__(256, 1) void nerf_colour_kernel_bf16(const ColourArgs A) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const LDS_AS char *lds = (const LDS_AS char *)smem;
@@ -814,3 +848,33 @@ hipError_t nerf_mlp_bf16v2_launch(const MlpArgs &a, bool full, int n_blocks, hip
         return full ? launch_t<true, MLP_MODE_POINTS>(a, n_blocks, stream) : hipErrorInvalidValue; // no sigma-only forward_batch
     return full ? launch_t<true, MLP_MODE_RAYS>(a, n_blocks, stream) : launch_t<false, MLP_MODE_RAYS>(a, n_blocks, stream);
 }
+#else // NERF_V2_F16: the pre-filter's two launches (sigma only; certify_zero, nerf_api.cpp cert_pass)
+hipError_t nerf_prefilter_f16v2_init() {
+    const void *ks[2] = {(const void *)nerf_trunk_seq_kernel_f16v2<false>, (const void *)nerf_mlp_kernel_f16v2<false, MLP_MODE_RAYS>};
+    for (int i = 0; i < 2; ++i) {
+        hipError_t e = hipFuncSetAttribute(ks[i], hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytesBf16V2);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
+hipError_t nerf_trunk_seq_f16v2_launch(const SeqArgs &a, int n_blocks, hipStream_t stream) { // the ray-sequential pre-filter
+    if (a.n_rays <= 0 || a.samples_per_ray <= 0) return hipSuccess;
+    if (!a.prefilter) return hipErrorInvalidValue;
+    const long long wg_rays = ((long long)a.n_rays + 7) / 8; // eight ray cursors per workgroup
+    if (n_blocks > wg_rays) n_blocks = (int)wg_rays;
+    if (n_blocks < 1) n_blocks = 1;
+    hipLaunchKernelGGL(nerf_trunk_seq_kernel_f16v2<false>, dim3(n_blocks), dim3(256), kLdsBytesBf16V2, stream, a);
+    return hipGetLastError();
+}
+
+hipError_t nerf_mlp_f16v2_launch(const MlpArgs &a, int n_blocks, hipStream_t stream) { // the fused pre-filter over all samples (sigma only, ray mode)
+    if (a.n_points <= 0) return hipSuccess;
+    if (a.mode != MLP_MODE_RAYS) return hipErrorInvalidValue;
+    const int n_tiles = (a.n_points + kPointsPerBlockBf16V2 - 1) / kPointsPerBlockBf16V2;
+    if (n_blocks > n_tiles) n_blocks = n_tiles;
+    if (n_blocks < 1) n_blocks = 1;
+    hipLaunchKernelGGL((nerf_mlp_kernel_f16v2<false, MLP_MODE_RAYS>), dim3(n_blocks), dim3(256), kLdsBytesBf16V2, stream, a);
+    return hipGetLastError();
+}
+#endif

@@ -227,6 +227,22 @@ int upload_bf16_family(nerf_ctx *c, int which, const std::vector<float> &v1f) {
     }
     if (!d.wstream_x3) HIP_TRY(c, hipMalloc((void **)&d.wstream_x3, x3.size() * sizeof(uint16_t)));
     HIP_TRY(c, hipMemcpy(d.wstream_x3, x3.data(), x3.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    {   // the f16 twin of the bf16 v2 stream (certify_zero's pre-filter): the same pieces in the same order, f16-rounded
+        std::vector<uint16_t> hb, h2;
+        const bool fits = f16_stream_from_v1order(v1f, hb);
+        if (fits) {
+            bf16_v2_from_v1(hb, h2); // a permutation of 16-bit elements: the element type does not matter
+            if (h2.size() != v2.size()) return fail(c, NERF_ERR_SHAPE, "internal: f16 v2 stream size");
+            if (!d.wstream_f16v2) HIP_TRY(c, hipMalloc((void **)&d.wstream_f16v2, h2.size() * sizeof(uint16_t)));
+            HIP_TRY(c, hipMemcpy(d.wstream_f16v2, h2.data(), h2.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+        } else if (d.wstream_f16v2) {
+            HIP_TRY(c, hipFree(d.wstream_f16v2));
+            d.wstream_f16v2 = nullptr;
+        }
+        // certify_zero calibrates itself per network: margins start at the floors of the pre-filter this network gets
+        c->cert_prefilter_f16[which] = g_bf16_v2 && c->cert_allow_f16 && d.wstream_f16v2 != nullptr;
+        c->cert_margin[which] = c->cert_prefilter_f16[which] ? c->cert_margin_floor_f16[which] : c->cert_margin_floor[which];
+    }
     std::vector<uint16_t> x2;
     if (x2_stream_from_v1order(v1f, x2)) { // every weight inside the f16 range (the lego networks: |w| <= 8.3)
         if (x2.size() != (size_t)nerfmlp::kChunksFullF16X2 * nerfmlp::kChunkBytesF16X2 / 2) return fail(c, NERF_ERR_SHAPE, "internal: f16x2 stream size");
@@ -285,7 +301,7 @@ int upload_packed(nerf_ctx *c, int which, const std::vector<float> &ws, const st
     HIP_TRY(c, hipMemcpy(d.wstream, ws.data(), ws.size() * sizeof(float), hipMemcpyHostToDevice));
     HIP_TRY(c, hipMemcpy(d.small, sm.data(), sm.size() * sizeof(float), hipMemcpyHostToDevice));
     d.loaded = true;
-    c->cert_margin[which] = c->cert_margin_floor[which]; // certify_zero calibrates itself per network
+    c->cert_margin[which] = c->cert_margin_floor[which]; // certify_zero calibrates itself per network (upload_bf16_family, which follows, decides the pre-filter)
     return NERF_OK;
 }
 
@@ -330,6 +346,7 @@ struct CertOutcome {
     float max_err[2] = {0.0f, 0.0f};          // max over them of |bf16 - exact pre-activation|
     uint64_t listed[2] = {0, 0};      // samples the exact kernel evaluated (both launches, audited certificates included)
     uint64_t fallback_rays = 0;       // rays whose predicted cut the exact transmittance did not confirm
+    uint64_t range_left[2] = {0, 0};  // f16 pre-filter: wave tiles in which an activation left the f16 range (the frame's certificates are void)
     uint64_t list_need = 0;           // largest list any pass wanted ...
     uint64_t list_capacity = 0;       // ... and what it had
     uint64_t pass_samples = 0;        // samples of the largest network pass (the list's worst case)
@@ -551,9 +568,13 @@ int render_once(nerf_ctx *c, const nerf_camera *cam, const nerf_render_opts *o, 
             const int n_pts = n_rays * spr;
             unsigned int *slots = c->d_cert + kCertSlots * (2 * (size_t)passes + which);
             const unsigned cap = (unsigned)std::min<size_t>(cert_cap, (size_t)n_pts);
+            // the pre-filter's arithmetic: f16 where the network fits its range (8 x closer to the exact pre-activations: tighter margins, a shorter
+            // list), else bf16; a tile of the f16 pass that saw an activation leave the range counts in slots[12] and render_device goes back to bf16
+            const bool pf16 = c->cert_prefilter_f16[which];
+            const float *pf_stream = pf16 ? (const float *)net.wstream_f16v2 : stream_of(net, NERF_MLP_BF16);
             MlpArgs b = a;
-            b.wstream = stream_of(net, NERF_MLP_BF16); b.small_params = net.small; b.n_points = n_pts; b.samples_per_ray = spr; b.t = t_in;
-            b.sigma_out = sigma_out; b.rgb_out = nullptr; b.raw_pre = 1; b.skip_empty = 0; b.skip_counter = nullptr; b.nonfinite = nullptr;
+            b.wstream = pf_stream; b.small_params = net.small; b.n_points = n_pts; b.samples_per_ray = spr; b.t = t_in;
+            b.sigma_out = sigma_out; b.rgb_out = nullptr; b.raw_pre = 1; b.skip_empty = 0; b.skip_counter = nullptr; b.nonfinite = pf16 ? slots + 12 : nullptr;
             const int kind_side = which == 0 && !rgb_out ? 0 : 4;
             {
                 Timed t(c, st, kind_side, 0, timing);
@@ -562,13 +583,14 @@ int render_once(nerf_ctx *c, const nerf_camera *cam, const nerf_render_opts *o, 
                     // later than k_cert_plan will (depth + 0.5): samples it never reaches stay NaN = "not evaluated" = uncertain
                     HIP_TRY(c, hipMemsetAsync(sigma_out, 0xFF, (size_t)n_pts * sizeof(float), st));
                     SeqArgs q{};
-                    q.wstream = stream_of(net, NERF_MLP_BF16); q.small_params = net.small; q.n_rays = n_rays; q.samples_per_ray = spr;
+                    q.wstream = pf_stream; q.small_params = net.small; q.n_rays = n_rays; q.samples_per_ray = spr;
                     q.ray_dirs = c->d_dirs; q.t = t_in; q.far_ = cam->far_;
                     q.origin[0] = cam->pos[0]; q.origin[1] = cam->pos[1]; q.origin[2] = cam->pos[2];
                     q.sigma_out = sigma_out; q.ray_counter = slots + 8; q.stats = (unsigned long long *)(slots + 10);
                     q.prefilter = 1; q.prefilter_cut_T = expf(-(c->cert_depth_limit + 0.5f));
-                    HIP_TRY(c, nerf_trunk_seq_bf16_launch(q, false, c->n_cus, st));
-                } else HIP_TRY(c, launch_mlp(c, NERF_MLP_BF16, b, false, st));
+                    q.nonfinite = pf16 ? slots + 12 : nullptr;
+                    HIP_TRY(c, pf16 ? nerf_trunk_seq_f16v2_launch(q, c->n_cus, st) : nerf_trunk_seq_bf16_launch(q, false, c->n_cus, st));
+                } else HIP_TRY(c, pf16 ? nerf_mlp_f16v2_launch(b, c->n_cus, st) : launch_mlp(c, NERF_MLP_BF16, b, false, st));
                 CertPlanArgs p{};
                 p.pre = sigma_out; p.t = t_in; p.n_rays = n_rays; p.spr = spr; p.far_ = cam->far_;
                 p.margin = c->cert_margin[which]; p.depth_limit = c->cert_depth_limit;
@@ -717,6 +739,7 @@ int render_once(nerf_ctx *c, const nerf_camera *cam, const nerf_render_opts *o, 
                 cert->headroom[w] = std::min(cert->headroom[w], hr); cert->max_err[w] = std::max(cert->max_err[w], er);
             }
             cert->fallback_rays += q[6];
+            cert->range_left[w] += q[12];
         }
     }
     if (stats) {
@@ -816,7 +839,14 @@ int nerfint::render_device(nerf_ctx *c, const nerf_camera *cam, const nerf_rende
             again = true;
             why = "the sample list was too short";
         }
-        const bool overflow = again; // an attempt whose list was too short evaluated only a part of it: its audit says nothing
+        for (int w = 0; w < 2; ++w)
+            if (oc.range_left[w]) { // the f16 pre-filter met an activation beyond 65 504: its pre-activations are void -- bf16 (f32's range) from now on
+                c->cert_prefilter_f16[w] = false;
+                c->cert_margin[w] = std::max(c->cert_margin[w], c->cert_margin_floor[w]);
+                again = true;
+                why = "an activation left the range of the f16 pre-filter";
+            }
+        const bool overflow = again; // an attempt whose list was too short evaluated only a part of it (or whose pre-filter left its range): its audit says nothing
         if (!overflow) violations += oc.violations[0] + oc.violations[1];
         for (int w = 0; w < 2 && !overflow; ++w) {
             if (!oc.used[w] || !oc.audited[w]) continue;
@@ -893,6 +923,8 @@ int nerf_create(int device_id, nerf_ctx **out) try {
     }
 #ifdef NERF_CERT_TUNING // variant builds only (make variant DEFS=-DNERF_CERT_TUNING=1): the product's certificates are not configurable from the environment
     if (const char *env = getenv("NERF_CERTIFY_SEQ_PREFILTER")) c->cert_seq_prefilter = atoi(env) != 0;
+    if (const char *env = getenv("NERF_CERTIFY_PREFILTER_F16")) c->cert_allow_f16 = atoi(env) != 0;
+    if (const char *env = getenv("NERF_CERTIFY_MARGINS_F16")) { float m0 = 0.f, m1 = 0.f; if (sscanf(env, "%f,%f", &m0, &m1) == 2 && m0 > 0.f && m1 > 0.f) { c->cert_margin_floor_f16[0] = m0; c->cert_margin_floor_f16[1] = m1; } }
     if (const char *env = getenv("NERF_CERTIFY_ZERO_TILES")) c->cert_zero_tiles = atoi(env) != 0;
     if (const char *env = getenv("NERF_CERTIFY_ZERO_FRAC")) { const double v = atof(env); if (v > 0.0 && v <= 1.0) c->cert_zero_frac = (float)v; }
     if (const char *env = getenv("NERF_CERTIFY_CUT_DEPTH")) { const double v = atof(env); if (v > 0.0) c->cert_depth_limit = (float)v; }
@@ -917,6 +949,7 @@ int nerf_create(int device_id, nerf_ctx **out) try {
         if (!init_done.count(device_id)) {
             e1 = nerf_mlp_init();
             if (e1 == hipSuccess) e1 = nerf_mlp_bf16v2_init();
+            if (e1 == hipSuccess) e1 = nerf_prefilter_f16v2_init();
 #if NERF_BF16_V3
             if (e1 == hipSuccess) e1 = nerf_mlp_bf16v3_init();
 #endif
@@ -944,7 +977,7 @@ void nerf_destroy(nerf_ctx *c) {
     if (!c) return;
     DeviceGuard dg(c->device);
     (void)hipDeviceSynchronize();
-    for (auto &n : c->net) { if (n.wstream) (void)hipFree(n.wstream); if (n.small) (void)hipFree(n.small); if (n.wstream_bf16v2) (void)hipFree(n.wstream_bf16v2); if (n.wstream_bf16v3) (void)hipFree(n.wstream_bf16v3); if (n.wstream_x3) (void)hipFree(n.wstream_x3); if (n.wstream_x2) (void)hipFree(n.wstream_x2); }
+    for (auto &n : c->net) { if (n.wstream) (void)hipFree(n.wstream); if (n.small) (void)hipFree(n.small); if (n.wstream_bf16v2) (void)hipFree(n.wstream_bf16v2); if (n.wstream_bf16v3) (void)hipFree(n.wstream_bf16v3); if (n.wstream_x3) (void)hipFree(n.wstream_x3); if (n.wstream_x2) (void)hipFree(n.wstream_x2); if (n.wstream_f16v2) (void)hipFree(n.wstream_f16v2); }
     float *ptrs[] = {c->d_dirs, c->d_tc, c->d_sc, c->d_rgbc, c->d_tf, c->d_sf, c->d_rgbf, c->d_rayfb, c->d_out};
     for (float *p : ptrs) if (p) (void)hipFree(p);
     if (c->d_scratch) (void)hipFree(c->d_scratch);

@@ -18,6 +18,7 @@ struct DevNet {
     uint16_t *wstream_bf16v3 = nullptr; // bf16 pieces for the 16x16x32 kernel (mlp_kernel_bf16v3.hip)
     uint16_t *wstream_x3 = nullptr;     // three bf16 parts per weight (mlp_kernel_bf16x3.hip)
     uint16_t *wstream_x2 = nullptr;     // two f16 parts per weight (mlp_kernel_f16x2.hip); NULL if a weight exceeds the f16 range
+    uint16_t *wstream_f16v2 = nullptr;  // one f16 per weight in wstream_bf16v2's order (mlp_kernel_f16v2.hip: certify_zero's pre-filter); NULL likewise
     bool loaded = false;
 };
 
@@ -28,6 +29,10 @@ struct DevNet {
 // (C3 frame, exact evaluations: tools/sweep_certify_margins.py): coarse 0.5 -> 8.2 %, 1.0 -> 12.2 %, 1.5 -> 18.6 % of the samples; fine 2 -> 18.8 %,
 // 3 -> 20.7 %, 4 -> 23.3 %.
 constexpr float kCertMarginCoarse = 1.0f, kCertMarginFine = 3.0f;
+// The same floors when the pre-filter runs in f16 (mlp_kernel_f16v2.hip; the default wherever the network's weights fit the f16 range): its
+// pre-activations are 8 x closer to the exact ones (numpy emulation on lego rays: largest |f16 - f32| on true zeros 0.048 coarse / 0.113 fine
+// against bf16's 0.20 / 0.87), so the margins can be tighter by about that factor with the same distance between floor and largest audited error.
+constexpr float kCertMarginCoarseF16 = 0.25f, kCertMarginFineF16 = 0.5f;
 
 struct EvPair {
     hipEvent_t a, b;
@@ -65,6 +70,9 @@ struct nerf_ctx {
     unsigned int *d_cert_aux = nullptr; size_t cert_aux_bytes = 0;     // {sample, bf16 pre-activation} of the audited certificates of a launch
     float cert_margin[2] = {nerfint::kCertMarginCoarse, nerfint::kCertMarginFine}; // widened by render_device when an audit fails; reset at load
     float cert_margin_floor[2] = {nerfint::kCertMarginCoarse, nerfint::kCertMarginFine};
+    float cert_margin_floor_f16[2] = {nerfint::kCertMarginCoarseF16, nerfint::kCertMarginFineF16};
+    bool cert_prefilter_f16[2] = {false, false}; // per network: the pre-filter runs in f16 (set at load when the weights fit; cleared for good when an activation left the f16 range)
+    bool cert_allow_f16 = true;
     float cert_depth_limit = 9.6f;        // predicted cut: bf16 optical depth > 9.6 (the exact cut is at T < 1e-4 = depth 9.21; nothing but work depends on it:
                                           // lego frame 0 rays fall back at 9.5, 25 at 9.35, 1132 of 640 000 at 9.25 -- tools/sweep_certify.py)
     unsigned cert_audit_mask = 127;       // one certified sample in 128 is audited ...

@@ -454,7 +454,7 @@ __global__ __launch_bounds__(256) void k_cert_plan(CertPlanArgs a) {
             const int i = g0 + lane;
             const bool in = i < spr;
             const float pre = in ? pre_q[q] : 0.0f, od = in ? od_q[q] : 0.0f;
-            const bool unc = in && !(pre < -a.margin);
+            const bool unc = in && !(pre < -a.margin && pre >= -3.0e38f); // NaN, +-inf (an f16 pre-filter that left its range) are never certificates
             bool dead = jstar < spr; // a previous group already reached the predicted cut
             if (!dead) {
                 float v = od;

@@ -1,4 +1,4 @@
-"""certify_zero (nerf_render_opts.certify_zero, ABI 5): a bf16 pass over all samples (Z) certifies those whose density pre-activation is
+"""certify_zero (nerf_render_opts.certify_zero, ABI 5): a 16-bit pass over all samples (f16 where the network fits its range, else bf16) (Z) certifies those whose density pre-activation is
 far below 0 and (C) predicts each ray's T < 1e-4 cut (src/lib.rs:276-279); the exact kernel (nerf_mlp_kernel<.., MLP_MODE_LIST>; for the
 fine pass of a split arithmetic that arithmetic's kernel) evaluates only the other samples in front of the predicted cut, the exact
 transmittance confirms the cut.  A certified sample has sigma = 0 in the exact network too, hence weight 0 (src/lib.rs:271-272), a
@@ -18,6 +18,9 @@ pytestmark = pytest.mark.gpu
 
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 
+FLOORS_F16 = (0.25, 0.5)   # nerf_internal.h kCertMargin*F16: the pre-filter runs in f16 (lego: every weight and activation inside the f16 range)
+FLOORS_BF16 = (1.0, 3.0)   # kCertMarginCoarse / Fine: the bf16 pre-filter (f32's range)
+
 
 def test_c3_whole_frame_is_the_f32_frame(renderer, native, samples):
     cam = native.camera_from_samples(samples, 800, 800, 64)
@@ -30,10 +33,10 @@ def test_c3_whole_frame_is_the_f32_frame(renderer, native, samples):
           f"{st.certify_headroom} at margins {st.certify_margin}, {st.n_certify_fallback_rays} of {st.n_rays} rays fell back, {st.n_certify_retries} retries")
     # work fractions only (timing ratios are bench output: a throttled box must not turn a correctness suite red)
     assert 0.05 < fc < 0.45 and 0.08 < ff < 0.3 and 0.6 * st.n_exec_fine_trunk < st.n_exec_colour < st.n_exec_fine_trunk   # probable zeros and audited certificates skip the colour head tile-wise
-    assert st.n_certify_retries == 0 and st.n_certify_violations == 0 and st.certify_margin == (1.0, 3.0)
+    assert st.n_certify_retries == 0 and st.n_certify_violations == 0 and st.certify_margin == FLOORS_F16
     certified = st.n_coarse_points + st.n_fine_points - st.n_exec_coarse_trunk - st.n_exec_fine_trunk
     # audited: 1 in 16 of the samples certified by less than twice the margin, 1 in 128 of the others (in front of the predicted cuts)
-    assert certified / 128 * 0.9 < st.n_certify_audited < certified / 16
+    assert certified / 128 * 0.8 < st.n_certify_audited < certified / 16
     assert all(h >= 0.5 * m for h, m in zip(st.certify_headroom, st.certify_margin))
     assert st.n_certify_fallback_rays < 0.01 * st.n_rays
 
@@ -129,7 +132,7 @@ def _load(native, r, root):
 
 
 def test_hot_network_widens_its_margins_instead_of_differing(native, samples, tmp_path):
-    """Pre-activations 40 x the lego networks': bf16 is off by up to tens on zero-density samples, the shipped margins (1 / 3) certify
+    """Pre-activations 40 x the lego networks': the 16-bit pass is off by several units on zero-density samples, the shipped margins certify
     samples whose exact density is positive.  The audit must see it (violations, or headroom below half the margin), widen the
     margins and render again: the frame returned is the plain frame of that network, and the next frame starts from the widened margins."""
     with native.Renderer(0) as r:
@@ -140,7 +143,7 @@ def test_hot_network_widens_its_margins_instead_of_differing(native, samples, tm
         img, st = native.render_image(r.coarse, r.fine, cam, 128, seed=3, crop=crop, certify_zero=True, return_stats=True)
         print(f"\nhot network: {st.n_certify_retries} retries, {st.n_certify_violations} violations seen, margins {st.certify_margin}, headroom {st.certify_headroom}")
         assert np.array_equal(img, ref)
-        assert st.n_certify_retries >= 1 and max(st.certify_margin) > 3.0
+        assert st.n_certify_retries >= 1 and all(m > 2 * f for m, f in zip(st.certify_margin, FLOORS_F16))
         assert all(h >= 0.5 * m for h, m in zip(st.certify_headroom, st.certify_margin))
         img2, st2 = native.render_image(r.coarse, r.fine, cam, 128, seed=4, crop=crop, certify_zero=True, return_stats=True)
         # the next frame starts from the widened margins (another seed's audit may widen them further, never back)
@@ -148,7 +151,41 @@ def test_hot_network_widens_its_margins_instead_of_differing(native, samples, tm
         assert np.array_equal(img2, native.render_image(r.coarse, r.fine, cam, 128, seed=4, crop=crop))
         _load(native, r, SCENE)  # loading a network resets its margin
         _, st3 = native.render_image(r.coarse, r.fine, cam, 128, seed=4, crop=crop, certify_zero=True, return_stats=True)
-        assert st3.certify_margin == (1.0, 3.0) and st3.n_certify_retries == 0 and st3.n_certify_violations == 0
+        assert st3.certify_margin == FLOORS_F16 and st3.n_certify_retries == 0 and st3.n_certify_violations == 0
+
+
+def test_network_beyond_the_f16_range_falls_back_to_the_bf16_prefilter(native, samples, tmp_path):
+    """dense0 x 2000, dense1 x 50: activations beyond 65 504 -- the f16 pre-filter's pre-activations come out non-finite there (never certified, and
+    counted); render_device goes back to the bf16 pre-filter for that network, for good, and renders the frame again.  The frame returned is the
+    plain f32 frame; the margins are the bf16 pass's from then on (at least its floors: such a network's errors widen them further)."""
+    import shutil
+    root = tmp_path / "big"
+    shutil.copytree(SCENE, root)
+    for which in ("coarse", "fine"):
+        for t, k in (("dense0_kernel", 2000.0), ("dense0_bias", 2000.0), ("dense1_kernel", 50.0), ("dense1_bias", 50.0)):
+            f = root / which / f"{t}.bin"
+            (np.fromfile(f, "<f4") * np.float32(k)).astype("<f4").tofile(f)
+    with native.Renderer(0) as r:
+        _load(native, r, root)
+        cam = native.camera_from_samples(samples, 400, 400, 64)
+        crop = (100, 120, 200, 100)
+        ref = native.render_image(r.coarse, r.fine, cam, 128, seed=3, crop=crop)
+        try:
+            img, st = native.render_image(r.coarse, r.fine, cam, 128, seed=3, crop=crop, certify_zero=True, return_stats=True)
+        except native.NerfError as e:   # eight widenings may not reach a network this far out: loud, never silently different
+            print("\nbeyond the f16 range:", e.msg)
+            assert e.code == -6 and "certify_zero" in e.msg
+        else:
+            print(f"\nbeyond the f16 range: {st.n_certify_retries} retries, margins {st.certify_margin}, lists {st.n_exec_coarse_trunk / st.n_coarse_points:.3f} / "
+                  f"{st.n_exec_fine_trunk / st.n_fine_points:.3f}")
+            assert np.array_equal(img, ref)
+            assert st.n_certify_retries >= 1 and all(m >= f for m, f in zip(st.certify_margin, FLOORS_BF16))
+            img2, st2 = native.render_image(r.coarse, r.fine, cam, 128, seed=4, crop=crop, certify_zero=True, return_stats=True)
+            assert np.array_equal(img2, native.render_image(r.coarse, r.fine, cam, 128, seed=4, crop=crop))
+            assert all(m >= f for m, f in zip(st2.certify_margin, FLOORS_BF16))   # no way back to f16 until the network is loaded again
+        _load(native, r, SCENE)
+        _, st3 = native.render_image(r.coarse, r.fine, cam, 128, seed=4, crop=crop, certify_zero=True, return_stats=True)
+        assert st3.certify_margin == FLOORS_F16 and st3.n_certify_retries == 0
 
 
 def test_uncertifiable_network_fails_loudly_or_is_exact(native, samples, tmp_path):
@@ -188,4 +225,4 @@ def test_random_weight_fogs(native, samples, tmp_path, kw):
         assert st.n_certify_retries == (1 if W == 400 else 0)   # the list grew once (a fog lists every sample), no margin moved
         img2, st2 = native.render_image(r.coarse, r.fine, cam, 128, seed=6, certify_zero=True, return_stats=True)
         assert np.array_equal(img2, native.render_image(r.coarse, r.fine, cam, 128, seed=6))
-        assert st2.n_certify_retries == 0 and st2.certify_margin == st.certify_margin == (1.0, 3.0)
+        assert st2.n_certify_retries == 0 and st2.certify_margin == st.certify_margin == FLOORS_F16

@@ -11,7 +11,7 @@ mkdir -p build/$NAME
 OBJ=build/$NAME/${FILE%.hip}.o
 FLAGS="-O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-result --offload-arch=gfx950"
 EXTRA=""
-[ "$FILE" = "mlp_kernel_bf16v2.hip" ] && EXTRA="-mllvm -amdgpu-mfma-vgpr-form=1"   # as in the Makefile
+{ [ "$FILE" = "mlp_kernel_bf16v2.hip" ] || [ "$FILE" = "mlp_kernel_f16v2.hip" ]; } && EXTRA="-mllvm -amdgpu-mfma-vgpr-form=1"   # as in the Makefile
 /opt/rocm/bin/hipcc $FLAGS $EXTRA $DEFS -c $FILE -o $OBJ
 TAG="-DNERF_BUILD_VARIANT=\"$NAME: ${FILE} ${DEFS//\"/}\""
 /opt/rocm/bin/hipcc $FLAGS "$TAG" -x hip -c nerf_host_api.cpp -o build/$NAME/nerf_host_api.o
