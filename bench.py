@@ -458,7 +458,7 @@ def main():
     # (three bf16 parts, six products; DESIGN 4.7 f16x2: two f16 parts, three products), each also with
     # exact dead-sample skipping on top.  The coarse (sampling) pass stays on the f32 MFMA kernel in both.
     # Reported separately, never part of `value`: zero certification -- the same f32 frame, bit for bit, with the f32 kernel
-    # evaluating only the samples a bf16 pass could not certify as zero-density.
+    # evaluating only the samples a 16-bit pass (f16 where the network fits its range, else bf16) could not certify as zero-density.
     extra_cert = None
     if world == 1 and args.dtype == "f32" and not args.skip_empty and not args.skip_dead and not args.certify_zero and not args.no_extra:
         def cert_step(stats=False):
@@ -481,10 +481,10 @@ def main():
                       "device_ms": {"total": st.ms_total, "coarse_bf16_pass_plus_f32_list": st.ms_coarse_mlp, "fine_bf16_pass_plus_f32_list": st.ms_fine_mlp, "other": st.ms_other},
                       "audit": {"certified_samples_evaluated_all_the_same": st.n_certify_audited, "violations": st.n_certify_violations,
                                 "margins_coarse_fine": list(st.certify_margin), "least_headroom_coarse_fine": list(st.certify_headroom),
-                                "largest_bf16_error_on_an_audited_certificate_coarse_fine": list(st.certify_max_error),
+                                "largest_prefilter_error_on_an_audited_certificate_coarse_fine": list(st.certify_max_error),
                                 "frame_rendered_again": st.n_certify_retries},
                       "rays_whose_predicted_cut_was_not_confirmed": st.n_certify_fallback_rays,
-                      "note": "opt-in certify_zero (DESIGN 4.9): a bf16 pass over all samples certifies those whose density pre-activation is below minus the "
+                      "note": "opt-in certify_zero (DESIGN 4.9): a 16-bit pass (f16 operands where the network fits the f16 range -- lego does --, else bf16) over all samples certifies those whose density pre-activation is below minus the "
                               "network's margin as zeros of the f32 network too and predicts each ray's T < 1e-4 cut; the f32 MFMA kernel evaluates only the "
                               "other samples in front of the predicted cut (a device-side list), the exact transmittance confirms the cut; certified samples "
                               "and samples behind the cut have weight 0, so the frame is the headline frame bit for bit; one certified sample in 64 is "
@@ -691,7 +691,7 @@ def main():
                          "kernel": ((f"nerf_trunk_seq_kernel_{sfx}<EXPORT=true> (fine network, ray-sequential trunk; executed flops)" if two_launch else
                                      "nerf_trunk_seq_kernel<EXPORT=true> (fine network, ray-sequential trunk + in-kernel colour passes; executed flops)")
                                     if dead_stats is not None else
-                                    ("nerf_mlp_kernel" + ("_bf16x3" if x3 else "_f16x2" if x2 else "") + "<FULL=true, MODE_LIST> (fine network, the samples a bf16 pass could neither certify as zeros nor place behind the cut; executed flops)")
+                                    ("nerf_mlp_kernel" + ("_bf16x3" if x3 else "_f16x2" if x2 else "") + "<FULL=true, MODE_LIST> (fine network, the samples a 16-bit pass could neither certify as zeros nor place behind the cut; executed flops)")
                                     if cert_stats is not None else
                                     ("nerf_mlp_kernel_bf16v2" if bf16 else "nerf_mlp_kernel_bf16x3" if x3 else "nerf_mlp_kernel_f16x2" if x2 else "nerf_mlp_kernel") +
                                     "<FULL=true, MODE_RAYS> (fine network)"),

@@ -100,22 +100,25 @@ typedef struct {
                            * found 0.9 unflagged rays per million beyond it, the largest at 2.8e-5.  Not bit-identical to
                            * hybrid_sampling = 0 (pixels differ by 2e-8 on average); held to the same Gate 1.
                            * nerf_stats.n_hybrid_rays = rays redone in f32. */
-    int32_t certify_zero;  /* ext (ABI 4, reworked in ABI 5; mlp_dtype F32, BF16X3 or F16X2, no skip mode): 1 = a bf16 pass over all samples finds
+    int32_t certify_zero;  /* ext (ABI 4, reworked in ABI 5; mlp_dtype F32, BF16X3 or F16X2, no skip mode): 1 = a 16-bit pass over all samples (f16 operands where
+                           * every weight and activation of the network fits the f16 range, else bf16; f32 accumulation either way) finds
                            * (Z) the samples whose density pre-activation is so far below 0 (per-network margin, see below) that the exact
                            * network's density is certainly 0 there as well, and predicts (C) where each ray's transmittance falls below the
                            * reference's 1e-4 cut (src/lib.rs:276-279: every later weight is zero-filled whatever its density).  The exact kernel
                            * -- for the fine pass of a split arithmetic that arithmetic's kernel -- evaluates only the other samples in front of
-                           * the predicted cut (a device-side list: 12 % of the coarse, 21 % of the fine samples of the lego frame); the
+                           * the predicted cut (a device-side list: 7 % of the coarse, 15 % of the fine samples of the lego frame); the
                            * EXACT transmittance then confirms each cut, and where it does not (rare) the rest of that ray is evaluated in a
                            * second launch -- so (C) is exact by construction.  A certified sample has sigma = 0, weight 0 (src/lib.rs:271-272):
                            * the image is BIT-IDENTICAL to certify_zero = 0 as long as no certificate (Z) is wrong.
                            * (Z) rests on measurements, not on a proof, so it is AUDITED in every frame: one certified sample in 64 (1 in 16 of those certified by
                            * less than twice the margin, 1 in 128 of the others) is evaluated
-                           * exactly all the same; a positive density there (nerf_stats.n_certify_violations), or an audited sample on which the bf16
+                           * exactly all the same; a positive density there (nerf_stats.n_certify_violations), or an audited sample on which the 16-bit
                            * pass was off by more than half the margin (nerf_stats.certify_max_error, certify_headroom), widens that network's margin for the life of
-                           * the context (floors: 1.0 coarse, 3.0 fine -- 2.5-5 x the largest bf16-vs-f32 difference the audits see on certified samples of
-                           * the lego networks; reset when a network is loaded) and the frame is rendered again (nerf_stats.n_certify_retries); if
-                           * 8 widenings do not satisfy the audit the render fails with NERF_ERR_STATE.  A network on which bf16 is less accurate
+                           * the context (floors: 0.25 coarse, 0.5 fine with the f16 pass, 1.0 / 3.0 with the bf16 pass -- 2.5-9 x the largest difference to the
+                           * exact pre-activation the audits see on certified samples of the lego networks; reset when a network is loaded) and the frame is rendered again (nerf_stats.n_certify_retries); if
+                           * 8 widenings do not satisfy the audit the render fails with NERF_ERR_STATE.  An activation beyond 65 504 makes the f16 pass's
+                           * pre-activations non-finite (never certified, counted): that network goes back to the bf16 pass for good and the frame is
+                           * rendered again.  A network on which the 16-bit pass is less accurate
                            * thus calibrates itself, certifies nothing (random weights: pre-activations near 0), or fails loudly; what remains
                            * unobserved is a wrong certificate that is so rare that a 1-in-64 audit of ~1e8 certified samples per frame never
                            * meets one or its precursors.  Because of the audit a certify_zero render synchronises the stream before it returns
@@ -157,9 +160,9 @@ typedef struct {
     uint64_t n_certify_violations; /* audited samples whose exact density was positive, summed over ALL renders of this frame (the last one had none) */
     uint32_t n_certify_retries;    /* times the frame was rendered again (margins widened after a failed audit, or the sample list enlarged) */
     uint32_t n_certify_fallback_rays; /* rays whose predicted cut the exact transmittance did not confirm (their remaining samples went through a second launch) */
-    float certify_margin[2];       /* margins in force (coarse, fine network): a sample is certified iff its bf16 pre-activation < -margin */
+    float certify_margin[2];       /* margins in force (coarse, fine network): a sample is certified iff its 16-bit (f16 / bf16 pass) pre-activation < -margin */
     float certify_headroom[2];     /* min over the audited samples of -(exact pre-activation): how far the closest one stood from a positive density (inf: none audited) */
-    float certify_max_error[2];    /* max over the audited samples of |bf16 - exact pre-activation|: what the bf16 pass got wrong on a sample it certified */
+    float certify_max_error[2];    /* max over the audited samples of |16-bit - exact pre-activation|: what the pre-filter got wrong on a sample it certified */
 } nerf_stats;
 
 /* ---- lifecycle ------------------------------------------------------------------------------------------ */

@@ -39,7 +39,13 @@ def fuzz(r, budget, rng_seed):
                 tot["f16_range_errors"] = tot.get("f16_range_errors", 0) + 1
                 continue
             raise
-        img, st = N.render_image(r.coarse, r.fine, cam, nf, certify_zero=True, return_stats=True, **kw)
+        try:
+            img, st = N.render_image(r.coarse, r.fine, cam, nf, certify_zero=True, return_stats=True, **kw)
+        except N.NerfError as e:   # a network the 16-bit passes cannot certify fails loudly (NERF_ERR_STATE), never silently differently
+            if e.code == -6 and "certify_zero" in e.msg:
+                tot["failed_loudly"] = tot.get("failed_loudly", 0) + 1
+                continue
+            raise
         tot["cases"] += 1; tot["rays"] += st.n_rays
         tot["f32_samples_nominal"] += st.n_coarse_points + st.n_fine_points
         tot["f32_samples_evaluated"] += st.n_exec_coarse_trunk + st.n_exec_fine_trunk
@@ -56,20 +62,23 @@ def fuzz(r, budget, rng_seed):
 
 
 def scaled_scene(root, scale):
-    """lego with dense7 (kernel and bias) scaled: every density pre-activation, and the bf16 pass's error on it, grows by `scale`."""
+    """lego with dense7 (kernel and bias) scaled: every density pre-activation, and the 16-bit pass's error on it, grows by `scale`.
+    scale < 0 ("big" on the command line): dense0 x 2000 and dense1 x 50 instead -- activations beyond the f16 range, so the f16 pre-filter
+    must hand the network over to the bf16 one (and that one must calibrate itself on pre-activations of 1e6)."""
     import shutil
     for which in ("coarse", "fine"):
         shutil.copytree(os.path.join(ROOT, "lego_rust", which), os.path.join(root, which))
-        for t in ("dense7_kernel", "dense7_bias"):
+        for t, k in ((("dense7_kernel", scale), ("dense7_bias", scale)) if scale > 0 else
+                     (("dense0_kernel", 2000.0), ("dense0_bias", 2000.0), ("dense1_kernel", 50.0), ("dense1_bias", 50.0))):
             f = os.path.join(root, which, t + ".bin")
-            (np.fromfile(f, "<f4") * np.float32(scale)).astype("<f4").tofile(f)
+            (np.fromfile(f, "<f4") * np.float32(k)).astype("<f4").tofile(f)
     return root
 
 
 if __name__ == "__main__":
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-    scales = [float(x) for x in sys.argv[3].split(",")] if len(sys.argv) > 3 else [1.0]   # e.g. 1,3,10,40: hotter networks than lego
+    scales = [-1.0 if x == "big" else float(x) for x in sys.argv[3].split(",")] if len(sys.argv) > 3 else [1.0]   # e.g. 1,3,10,40,big: hotter networks than lego
     bad = 0
     for k, scale in enumerate(scales):
         import tempfile
