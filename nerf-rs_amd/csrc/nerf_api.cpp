@@ -469,7 +469,7 @@ int render_once(nerf_ctx *c, const nerf_camera *cam, const nerf_render_opts *o, 
         }
         if (hybrid && (rc = ensure_bytes(c, (void **)&c->d_flag_list, &c->flag_list_bytes, rows_per_pass * RW * sizeof(unsigned int)))) return rc;
     }
-    // Zero certification (nerf_render_opts.certify_zero; DESIGN 4.9, protocol: sampling_kernels.hip k_cert_*): a bf16 pass over all samples
+    // Zero certification (nerf_render_opts.certify_zero; DESIGN 4.9, protocol: sampling_kernels.hip k_cert_*): a 16-bit pass (f16 or bf16 operands, cert_prefilter_f16) over all samples
     // finds (Z) the samples whose density pre-activation is so far below 0 (margin per network, c->cert_margin: audited every frame and
     // widened by render_device when the audit's headroom shrinks) that the exact network's density is certainly 0 there too, and predicts
     // (C) where each ray's transmittance falls below the reference's 1e-4 cut; the exact kernel evaluates only the remaining samples in
@@ -562,7 +562,7 @@ int render_once(nerf_ctx *c, const nerf_camera *cam, const nerf_render_opts *o, 
         a.mode = MLP_MODE_RAYS;
         a.ray_dirs = c->d_dirs;
         a.origin[0] = cam->pos[0]; a.origin[1] = cam->pos[1]; a.origin[2] = cam->pos[2];
-        // zero certification: bf16 pre-activations of all samples -> plan (list 1, predicted cuts) -> exact kernel on list 1 -> audit ->
+        // zero certification: 16-bit pre-activations of all samples -> plan (list 1, predicted cuts) -> exact kernel on list 1 -> audit ->
         // exact transmittance confirms the cuts (list 2 = what is left of the rays it does not) -> exact kernel on list 2
         auto cert_pass = [&](const DevNet &net, int which, int dt, int spr, const float *t_in, float *sigma_out, float *rgb_out, int kind) -> int {
             const int n_pts = n_rays * spr;
@@ -596,7 +596,7 @@ int render_once(nerf_ctx *c, const nerf_camera *cam, const nerf_render_opts *o, 
                 p.margin = c->cert_margin[which]; p.depth_limit = c->cert_depth_limit;
                 p.audit_mask = c->cert_audit_mask; p.audit_mask_near = c->cert_audit_mask_near; p.audit_salt = (unsigned)(o->seed * 0x9E3779B97F4A7C15ull >> 32) + 0x632BE5ABu * passes + (unsigned)which;
                 p.list = c->d_point_list; p.count = slots; p.capacity = cap; p.jstar = c->d_jstar;
-                // full evaluations: probable zeros (bf16 pre-activation below -margin / 3: three times the largest bf16 error the lego audits see
+                // full evaluations: probable zeros (pre-filter pre-activation below -margin x cert_zero_frac: several times the largest pre-filter error the lego audits see
                 // is not needed for a skip -- a positive density among them only keeps its tile's colour heads) and the audited certificates go
                 // to the back part of the list, whose all-zero tiles skip the colour head (exact: skip_empty)
                 if (rgb_out && c->cert_zero_tiles) { p.count_back = slots + 9; p.zero_threshold = c->cert_margin[which] * c->cert_zero_frac; }
@@ -856,14 +856,14 @@ int nerfint::render_device(nerf_ctx *c, const nerf_camera *cam, const nerf_rende
             if (rule) {
                 c->cert_margin[w] = widened; again = true;
                 why = rule == 1 ? "an audited certificate was wrong" : rule == 2 ? "an audited certificate came closer to a positive density than half the margin"
-                                                                                 : "the bf16 pass was off by more than half the margin on an audited certificate";
+                                                                                 : "the 16-bit pass was off by more than half the margin on an audited certificate";
             }
         }
         if (stats) { stats->n_certify_retries = (uint32_t)attempt; stats->n_certify_violations = violations; }
         if (!again) return NERF_OK;
         if (attempt == kMaxRetries) {
             char msg[320];
-            snprintf(msg, sizeof msg, "certify_zero: %s after %d renders of this frame (margins now %g / %g): the bf16 pass cannot certify this network's "
+            snprintf(msg, sizeof msg, "certify_zero: %s after %d renders of this frame (margins now %g / %g): the 16-bit pass cannot certify this network's "
                      "zero densities; render with certify_zero = 0", why.c_str(), attempt + 1, (double)c->cert_margin[0], (double)c->cert_margin[1]);
             return fail(c, NERF_ERR_STATE, msg);
         }

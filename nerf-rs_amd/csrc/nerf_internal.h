@@ -22,7 +22,8 @@ struct DevNet {
     bool loaded = false;
 };
 
-// certify_zero: a sample is a certain zero iff its bf16 density pre-activation is below -margin.  Floors per network, set by the statistic
+// certify_zero: a sample is a certain zero iff its 16-bit (pre-filter) density pre-activation is below -margin.  Floors per network WITH THE bf16
+// PRE-FILTER (networks beyond the f16 range), set by the statistic
 // the audit watches -- the largest |bf16 - exact| on an audited certificate, which widens the margin above half of it: lego coarse 0.15-0.20
 // (a fifth of 1.0), fine 0.99-1.24 (a third to 0.41 of 3.0; at round 3's fine margin of 2 it would trip the rule on most frames).  Round 3's
 // fuzz without an audit: coarse 0.5 / fine 1.0 never differed in 10 031 frames, 0.25 / 0.5 did in 1 % of them.  What the floors cost in work
@@ -31,7 +32,8 @@ struct DevNet {
 constexpr float kCertMarginCoarse = 1.0f, kCertMarginFine = 3.0f;
 // The same floors when the pre-filter runs in f16 (mlp_kernel_f16v2.hip; the default wherever the network's weights fit the f16 range): its
 // pre-activations are 8 x closer to the exact ones (numpy emulation on lego rays: largest |f16 - f32| on true zeros 0.048 coarse / 0.113 fine
-// against bf16's 0.20 / 0.87), so the margins can be tighter by about that factor with the same distance between floor and largest audited error.
+// against bf16's 0.20 / 0.87), so the margins can be tighter by about that factor with the same distance between floor and largest audited error
+// (audited errors on lego: 0.03-0.055 / 0.12-0.17; floor sweep: profiles/r04_certify_f16_prefilter_margin_sweep.log -- fine 0.3 trips the half-margin rule).
 constexpr float kCertMarginCoarseF16 = 0.25f, kCertMarginFineF16 = 0.5f;
 
 struct EvPair {
@@ -67,7 +69,7 @@ struct nerf_ctx {
     unsigned int *d_point_list = nullptr; size_t point_list_bytes = 0; // samples the exact kernel evaluates (one list, reused by every launch)
     unsigned int *d_cert = nullptr; size_t cert_bytes = 0;             // counters, 8 per (pass, network)
     int *d_jstar = nullptr; size_t jstar_bytes = 0;                    // per ray of a pass: first sample behind the predicted cut
-    unsigned int *d_cert_aux = nullptr; size_t cert_aux_bytes = 0;     // {sample, bf16 pre-activation} of the audited certificates of a launch
+    unsigned int *d_cert_aux = nullptr; size_t cert_aux_bytes = 0;     // {sample, 16-bit (pre-filter) pre-activation} of the audited certificates of a launch
     float cert_margin[2] = {nerfint::kCertMarginCoarse, nerfint::kCertMarginFine}; // widened by render_device when an audit fails; reset at load
     float cert_margin_floor[2] = {nerfint::kCertMarginCoarse, nerfint::kCertMarginFine};
     float cert_margin_floor_f16[2] = {nerfint::kCertMarginCoarseF16, nerfint::kCertMarginFineF16};
@@ -79,8 +81,8 @@ struct nerf_ctx {
     unsigned cert_audit_mask_near = 15;   // ... and one in 16 of those certified by less than twice the margin: the same number of audits as a flat 1 in 64
                                           // on the lego frame, four times as many where a certificate is at risk
     bool cert_zero_tiles = true;          // probable zeros + audited certificates in the list's back part, evaluated with skip_empty
-    float cert_zero_frac = 0.1f;          // "probably zero": bf16 pre-activation below -margin x this (C3 frame: 1/2 -> 334.6 ms, 1/3 -> 333.1, 0.1 -> 330.5, 0.02 -> 331.0: tools/sweep_certify_zero_frac.py)
-    bool cert_seq_prefilter = true;       // bf16 pre-filter ray-sequential with its own predicted cut (false: the fused bf16 kernel over all samples)
+    float cert_zero_frac = 0.1f;          // "probably zero": pre-filter pre-activation below -margin x this (C3 frame: 1/2 -> 334.6 ms, 1/3 -> 333.1, 0.1 -> 330.5, 0.02 -> 331.0: tools/sweep_certify_zero_frac.py)
+    bool cert_seq_prefilter = true;       // 16-bit pre-filter ray-sequential with its own predicted cut (false: the fused 16-bit kernel over all samples)
     double cert_list_frac = 0.5;          // list capacity as a fraction of a pass's samples: what earlier frames needed + 25 %
     float hybrid_tau = 1e-5f;                                        // a draw predicted to move by more than this (in t) flags its ray
     size_t max_export_bytes = (size_t)16 << 30; // budget of d_h8: bounds the rays per pass of skip_dead in a SPLIT arithmetic (NERF_MAX_EXPORT_BYTES);

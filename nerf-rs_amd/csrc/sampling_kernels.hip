@@ -394,7 +394,7 @@ __global__ void k_box_downsample(const float *__restrict__ rays, float *__restri
 // ---- zero certification (nerf_render_opts.certify_zero): which samples does the exact kernel have to look at? ------------
 // `pre` holds the bf16 kernel's density PRE-activations of all samples of a pass (rays x spr).  Two exact facts of the reference make a
 // sample's exact evaluation unnecessary:
-//   (Z) its exact density is 0 (weight T * (1 - exp(-0 * delta)) = 0, src/lib.rs:271-272) -- CERTIFIED when the bf16 pre-activation is
+//   (Z) its exact density is 0 (weight T * (1 - exp(-0 * delta)) = 0, src/lib.rs:271-272) -- CERTIFIED when the 16-bit (pre-filter: f16 or bf16 operands) pre-activation is
 //       below -margin (margin = several times the bf16-vs-exact difference ever seen near 0; audited, see k_cert_audit);
 //   (C) it lies behind the ray's T < 1e-4 cut (src/lib.rs:276-279: every later weight is zero-filled whatever its density) -- PREDICTED
 //       from the bf16 densities, VERIFIED with the exact ones (k_cert_verify), so nothing rests on the prediction but the amount of work.
@@ -418,7 +418,7 @@ __device__ __forceinline__ bool cert_audit_pick(unsigned idx, unsigned salt, uns
     return (((idx ^ salt) * 0x9E3779B1u) >> 7 & mask) == 0u; // a fixed pseudo-random 1 / (mask + 1) of the sample indices
 }
 
-// dynamic LDS: 4 waves x (rays_per_wave x spr entries + kAuxStage {stage position, bf16 pre-activation} pairs)
+// dynamic LDS: 4 waves x (rays_per_wave x spr entries + kAuxStage {stage position, pre-filter pre-activation} pairs)
 constexpr int kAuxStage = 256; // audited certificates a wave can stage between two flushes (at most rays_per_wave x spr / 16 = 96 for 8 rays of 192 samples); beyond: not audited
 __global__ __launch_bounds__(256) void k_cert_plan(CertPlanArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned lds_u[];
@@ -504,7 +504,7 @@ __global__ __launch_bounds__(256) void k_cert_plan(CertPlanArgs a) {
     unsigned at_front = s_base[0], at_back = s_base[1], at_aux = s_base[2];
     for (int w = 0; w < wv; ++w) { at_front += s_cnt[w][0]; at_back += s_cnt[w][1]; at_aux += s_cnt[w][2]; }
     if (staged + staged_back == 0) return; // wave-uniform
-    if (n_aux) { // remember {sample, bf16 pre-activation} of the audited certificates; one that does not fit is not audited (flag cleared)
+    if (n_aux) { // remember {sample, pre-filter pre-activation} of the audited certificates; one that does not fit is not audited (flag cleared)
         for (unsigned k = lane; k < n_aux; k += 64) {
             const unsigned sp = aux_stage[2 * k];
             if (at_aux + k < a.aux_capacity) { a.aux[2 * (size_t)(at_aux + k)] = stage[sp] & 0x7fffffffu; a.aux[2 * (size_t)(at_aux + k) + 1] = aux_stage[2 * k + 1]; }
@@ -522,7 +522,7 @@ __global__ __launch_bounds__(256) void k_cert_plan(CertPlanArgs a) {
 // Exact transmittance over [0, j*) of every ray with a predicted cut (j* < spr): one wave per ray, alpha in parallel, the recurrence as
 // compute_weights has it (src/lib.rs:261-280; the same operations in the same order as weights_scan / k_composite above, on the same
 // buffer contents: exact densities of the listed samples, exact zeros of the certified ones).  If it falls below 1e-4 inside the prefix,
-// every sample from j* on has weight 0 whatever its density: the marks are cleared and the ray is done.  Otherwise (the bf16 prediction
+// every sample from j* on has weight 0 whatever its density: the marks are cleared and the ray is done.  Otherwise (the 16-bit prediction
 // was too optimistic) the marked samples are listed for the second exact launch.  LDS: 4 waves x spr floats.
 __global__ __launch_bounds__(256) void k_cert_verify(CertVerifyArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds_f[];
@@ -561,10 +561,10 @@ __global__ __launch_bounds__(256) void k_cert_verify(CertVerifyArgs a) {
     if (n_more && lane == 0 && a.fallback_rays) atomicAdd(a.fallback_rays, 1u);
 }
 
-// The audit of (Z): `aux` holds {sample, bf16 pre-activation} of the certified samples that went on the list with bit 31 set -- the exact
+// The audit of (Z): `aux` holds {sample, pre-filter pre-activation} of the certified samples that went on the list with bit 31 set -- the exact
 // kernel evaluated them all the same and left its RAW pre-activation in the density buffer.  A positive one is a VIOLATION (the
 // certificate was wrong; this sample now holds its true density, its unaudited siblings do not).  Otherwise -pre is how far the sample
-// stood from a positive density (HEADROOM = the minimum over the audited samples), and |pre_bf16 - pre_exact| is what the bf16 pass got
+// stood from a positive density (HEADROOM = the minimum over the audited samples), and |pre_16bit - pre_exact| is what the pre-filter got
 // wrong on a sample it certified (MAX ERROR, at any depth below 0 -- samples right at the margin are rare in a network with large
 // pre-activations, its errors are not).  The host widens the margin and renders again when either uses up more than half the margin.
 // The buffer entry is reset to the exact kernel's value for such a sample: relu(pre) = 0.
