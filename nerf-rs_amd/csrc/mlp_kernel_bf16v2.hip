@@ -37,12 +37,12 @@ using namespace mlpdev;
 #define NERF_V2_F16 0
 #endif
 #if NERF_V2_F16
-typedef _Float16 bf16x8 __attribute__((ext_vector_type(8))); // (the names stay: "the 16-bit operand type of this build")
-typedef _Float16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8))); // h16 = the 16-bit operand type of this build
+typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
 #define V2SYM(bf16_name, f16_name) f16_name
 #else
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 h16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 h16x2 __attribute__((ext_vector_type(2)));
 #define V2SYM(bf16_name, f16_name) bf16_name
 #endif
 typedef short s16x2 __attribute__((ext_vector_type(2)));
@@ -178,7 +178,7 @@ __device__ __forceinline__ void pipe_start(PipeV &P) {
 // further on.  Phase 8: chunk c + 1 must have landed (every wave waits for its own pieces, then the barrier) and chunk
 // c + kRS - 1's DMA starts into the slot chunk c - 1 occupied.
 template <int PH>
-__device__ __forceinline__ bf16x8 pipe_take(PipeV &P) {
+__device__ __forceinline__ h16x8 pipe_take(PipeV &P) {
     if constexpr (PH == 8) {
         // chunk c + 1 was issued kRS - 2 chunks ago; the 4 (kRS - 3) pieces of the chunks issued since may still be in
         // flight (VMEM returns in order; any compiler-issued access in between only makes this wait longer, never shorter)
@@ -193,7 +193,7 @@ __device__ __forceinline__ bf16x8 pipe_take(PipeV &P) {
         pipe_next_chunk(P);
     }
 #if NERF_BV2_DIAG_NO_LDS
-    if constexpr (PH != 0) { u32x4 a = P.a[0]; asm volatile("" : "+v"(a)); return __builtin_bit_cast(bf16x8, a); }
+    if constexpr (PH != 0) { u32x4 a = P.a[0]; asm volatile("" : "+v"(a)); return __builtin_bit_cast(h16x8, a); }
 #endif
 #if NERF_BV2_PAIR_READS
     static_assert(kAhead % 2 == 0, "paired reads need an even prefetch distance");
@@ -209,9 +209,9 @@ __device__ __forceinline__ bf16x8 pipe_take(PipeV &P) {
         }
         P.a[(PH + kAhead) % 8] = *(const LDS_AS u32x4 *)(P.rd_base + ((PH + kAhead) % 16) * 1024);
         P.a[(PH + kAhead + 1) % 8] = *(const LDS_AS u32x4 *)(P.rd_base + ((PH + kAhead + 1) % 16) * 1024);
-        return __builtin_bit_cast(bf16x8, a);
+        return __builtin_bit_cast(h16x8, a);
     } else {
-        return __builtin_bit_cast(bf16x8, P.a[PH % 8]);
+        return __builtin_bit_cast(h16x8, P.a[PH % 8]);
     }
 #else
     const u32x4 a = P.a[PH % 8];
@@ -222,7 +222,7 @@ __device__ __forceinline__ bf16x8 pipe_take(PipeV &P) {
         P.rd_base = P.ring_lane + off;
     }
     P.a[(PH + kAhead) % 8] = *(const LDS_AS u32x4 *)(P.rd_base + ((PH + kAhead) % 16) * 1024);
-    return __builtin_bit_cast(bf16x8, a);
+    return __builtin_bit_cast(h16x8, a);
 #endif
 }
 
@@ -275,7 +275,7 @@ __device__ __forceinline__ void pipe_dma(PipeV &P) {
 template <bool RELU>
 __device__ __forceinline__ uint32_t pack2(float x, float y) {
     const f32x2 p = {x, y};
-    bf16x2 c = __builtin_convertvector(p, bf16x2);
+    h16x2 c = __builtin_convertvector(p, h16x2);
     if (RELU) {
         s16x2 i = __builtin_bit_cast(s16x2, c);
         i = __builtin_elementwise_max(i, (s16x2){0, 0});
@@ -379,9 +379,9 @@ __device__ __forceinline__ void out_tile(const u32x4 (&in0)[KS], const u32x4 (&i
     static_for<0, KS>([&](auto ks_c) {
         constexpr int ks = decltype(ks_c)::value;
         constexpr int ph = (PH + ks) % 16;
-        const bf16x8 a = pipe_take<ph>(P);
-        if constexpr (ks == 0) c0 = MFMA16(a, __builtin_bit_cast(bf16x8, in0[ks]), bv);
-        else                   c0 = MFMA16(a, __builtin_bit_cast(bf16x8, in0[ks]), c0);
+        const h16x8 a = pipe_take<ph>(P);
+        if constexpr (ks == 0) c0 = MFMA16(a, __builtin_bit_cast(h16x8, in0[ks]), bv);
+        else                   c0 = MFMA16(a, __builtin_bit_cast(h16x8, in0[ks]), c0);
         BV2_PIN();
         if constexpr (EP != 0)
             static_for<0, 8>([&](auto pr_c) {
@@ -390,8 +390,8 @@ __device__ __forceinline__ void out_tile(const u32x4 (&in0)[KS], const u32x4 (&i
             });
         pipe_dma<ph>(P);
         BV2_PIN();
-        if constexpr (ks == 0) c1 = MFMA16(a, __builtin_bit_cast(bf16x8, in1[ks]), bv);
-        else                   c1 = MFMA16(a, __builtin_bit_cast(bf16x8, in1[ks]), c1);
+        if constexpr (ks == 0) c1 = MFMA16(a, __builtin_bit_cast(h16x8, in1[ks]), bv);
+        else                   c1 = MFMA16(a, __builtin_bit_cast(h16x8, in1[ks]), c1);
         BV2_PIN();
         if constexpr (EP != 0)
             static_for<0, 8>([&](auto pr_c) {
@@ -481,7 +481,7 @@ __device__ __forceinline__ void colour_layers(u32x4 (&X0)[16], u32x4 (&X1)[16], 
     }
     layer<18, 4, true, 3, true, false, 14, false>(V0, V1, Y0, Y1, C, small + kBiasViewOff, small, H, P, h); // viewdirs + rgb partial sums (:220-223)
     {   // viewdirs' 72 pieces end at phase 8; the stream carries 8 zero pieces up to the chunk end: step over them
-        bf16x8 d;
+        h16x8 d;
         d = pipe_take<8>(P);                   asm volatile("" ::"v"(d));
         d = pipe_take<9>(P);  pipe_dma<9>(P);  asm volatile("" ::"v"(d));
         d = pipe_take<10>(P);                  asm volatile("" ::"v"(d));
