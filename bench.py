@@ -615,6 +615,24 @@ def main():
             "executed_fraction_colour_head": st.n_exec_colour / max(st.n_fine_points, 1),
             "device_ms": {"total": st.ms_total, "coarse_trunk": st.ms_coarse_mlp, "fine_trunk_plus_colour": st.ms_fine_mlp, "other": st.ms_other,
                           "passes": st.n_passes}}
+        # ... and, beside the bf16 study, what the same geometry costs at f32 ACCURACY (Gate 1): f16x2 fine pass + certify_zero
+        def c5_x2_step(stats=False):
+            return N.render_image(r.coarse, r.fine, cam, args.fine, seed=args.seed, ssaa=2, dtype="f16x2", certify_zero=True,
+                                  device_out=frame.data_ptr(), stream=stream, return_stats=stats)
+        try:
+            c5_x2_step(); c5_x2_step(); torch.cuda.synchronize(dev)
+            t1 = time.perf_counter()
+            for _ in range(3):
+                c5_x2_step()
+            torch.cuda.synchronize(dev)
+            ms = 1e3 * (time.perf_counter() - t1) / 3
+            st = c5_x2_step(stats=True)
+            extra_c5["same_geometry_at_f32_accuracy_f16x2_certify_zero"] = {
+                "rays_per_s": n_r / (ms * 1e-3), "ms_per_step": ms,
+                "exact_fraction_coarse": st.n_exec_coarse_trunk / max(st.n_coarse_points, 1), "exact_fraction_fine": st.n_exec_fine_trunk / max(st.n_fine_points, 1),
+                "note": "not bf16: the f16x2 frame (Gate 1 against the CPU oracle at 800x800) at C5's geometry, for comparison with the bf16 rows above"}
+        except N.NerfError as e:
+            extra_c5["same_geometry_at_f32_accuracy_f16x2_certify_zero"] = {"error": e.msg}
         r.kernel_time_query(reset=True)
     # The timed region leaves the frame in HBM (`value` never includes PCIe); the host-pointer entry point additionally pays
     # one D2H copy of the frame (BASELINE.md section 4 counts it on the GPU side): measured here, reported beside `value`.
