@@ -4,13 +4,18 @@ activations after layer k to the density pre-activation, fitted on half of the s
 own activations): its error on true zeros, the most negative value it predicts for a LIVE sample, and what it could certify at 2 x / 3 x that margin.
 Result: after layers 1..6 the probes are off by tens to hundreds (fine network, after layer 6: median 1.4, p99 12.7, max 39; a live sample predicted at
 -51) and certify nothing; only the probe after layer 7 works -- that is the alpha head itself.  The density is decided in the last layers: no early exit.
-Needs /tmp/exp/rays.npy = [t_merged(192) | dir_hat(3) | t_coarse(64)] per ray from oracle_py.render_ray_debug (see tools/emulate_prefilter_error.py)."""
+No GPU: sample positions from the CPU oracle (1 500 random pixels of the 800 x 800 frame), as tools/emulate_prefilter_error.py."""
 import numpy as np, sys, os
-ROOT='/root/repo'; sys.path.insert(0,ROOT); sys.path.insert(0,ROOT+'/oracle'); sys.path.insert(0,ROOT+'/tools')
+ROOT=os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0,ROOT); sys.path.insert(0,ROOT+'/oracle'); sys.path.insert(0,ROOT+'/tools')
 import oracle_py as O
 from emulate_prefilter_error import load, enc, f16
-rays=np.load('/tmp/exp/rays.npy')
 cam=O.camera_from_samples(O.load_samples(ROOT+'/lego_rust/tf_reference_samples.json'),800,800)
+_co,_fi=O.Net(ROOT+'/lego_rust/coarse'),O.Net(ROOT+'/lego_rust/fine')
+_opts=O.make_opts(64,128,seed=0); _rng=np.random.default_rng(1); _rows=[]
+for _ in range(int(sys.argv[1]) if len(sys.argv)>1 else 1500):
+    _d=O.render_ray_debug(_co,_fi,cam,_opts,int(_rng.integers(0,800)),int(_rng.integers(0,800)))
+    _rows.append(np.concatenate([_d['t_merged'],_d['dir_hat'],_d['t_coarse']]))
+rays=np.array(_rows,np.float32)   # [t_merged(192) | dir_hat(3) | t_coarse(64)] per ray
 o=np.array(list(cam.pos),np.float32)
 def hidden(W,pts,rnd):
     e=enc(pts,10); h=e; H=[]
