@@ -46,6 +46,9 @@ hipError_t nerf_mlp_bf16v2_launch(const MlpArgs &a, bool full, int n_blocks, hip
 // mlp_kernel_f16v2.hip: the f16 twin of the bf16 kernel, sigma-only forms (certify_zero's pre-filter; MlpArgs / SeqArgs .nonfinite += tiles that left the f16 range)
 hipError_t nerf_prefilter_f16v2_init();
 hipError_t nerf_mlp_f16v2_launch(const MlpArgs &a, int n_blocks, hipStream_t stream);
+#ifdef NERF_V2_F16_FULL // experiment (variant builds only): the full f16 kernel
+hipError_t nerf_mlp_f16v2_full_launch(const MlpArgs &a, int n_blocks, hipStream_t stream);
+#endif
 // skip_dead in the bf16 arithmetic (same file): two ray cursors per wave; the trunk exports the bf16-packed relu(h8) of the live samples
 // (512 B per sample; capacity nerf_seq_h8_bytes_bf16) for nerf_colour_bf16_launch.  SeqArgs / ColourArgs are declared below.
 struct SeqArgs;

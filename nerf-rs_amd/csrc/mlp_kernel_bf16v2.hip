@@ -877,4 +877,17 @@ hipError_t nerf_mlp_f16v2_launch(const MlpArgs &a, int n_blocks, hipStream_t str
     hipLaunchKernelGGL((nerf_mlp_kernel_f16v2<false, MLP_MODE_RAYS>), dim3(n_blocks), dim3(256), kLdsBytesBf16V2, stream, a);
     return hipGetLastError();
 }
+#ifdef NERF_V2_F16_FULL // experiment (variant builds): the full f16 kernel, to price an f16 twin of the bf16 mode
+hipError_t nerf_mlp_f16v2_full_launch(const MlpArgs &a, int n_blocks, hipStream_t stream) {
+    if (a.n_points <= 0) return hipSuccess;
+    if (a.mode != MLP_MODE_RAYS) return hipErrorInvalidValue;
+    const int n_tiles = (a.n_points + kPointsPerBlockBf16V2 - 1) / kPointsPerBlockBf16V2;
+    if (n_blocks > n_tiles) n_blocks = n_tiles;
+    if (n_blocks < 1) n_blocks = 1;
+    static bool attr_set = false;
+    if (!attr_set) { (void)hipFuncSetAttribute((const void *)nerf_mlp_kernel_f16v2<true, MLP_MODE_RAYS>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytesBf16V2); attr_set = true; }
+    hipLaunchKernelGGL((nerf_mlp_kernel_f16v2<true, MLP_MODE_RAYS>), dim3(n_blocks), dim3(256), kLdsBytesBf16V2, stream, a);
+    return hipGetLastError();
+}
+#endif
 #endif

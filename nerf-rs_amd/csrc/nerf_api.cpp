@@ -112,7 +112,15 @@ static const float *stream_of(const DevNet &n, int dtype) {
     if (dtype == NERF_MLP_F32) return n.wstream;
     return g_bf16_v2 ? (const float *)n.wstream_bf16v2 : (const float *)n.wstream_bf16v3;
 }
+// NERF_V2_F16_FULL (experiment, variant builds): NERF_MLP_BF16 renders run the f16 twin of the bf16 kernel (fused ray-mode launches only)
 static hipError_t launch_mlp(const nerf_ctx *c, int dtype, const MlpArgs &a, bool full, hipStream_t st) {
+#ifdef NERF_V2_F16_FULL
+    if (dtype == NERF_MLP_BF16 && a.mode == MLP_MODE_RAYS && !a.raw_pre) {
+        MlpArgs b = a;
+        for (const DevNet &n : c->net) if ((const void *)n.wstream_bf16v2 == (const void *)a.wstream && n.wstream_f16v2) b.wstream = (const float *)n.wstream_f16v2;
+        return full ? nerf_mlp_f16v2_full_launch(b, c->n_cus, st) : nerf_mlp_f16v2_launch(b, c->n_cus, st);
+    }
+#endif
     if (dtype == NERF_MLP_F32) return nerf_mlp_launch(a, full, c->n_cus, st);
     if (dtype == NERF_MLP_BF16X3) return nerf_mlp_bf16x3_launch(a, full, c->n_cus, st);
     if (dtype == NERF_MLP_F16X2) return nerf_mlp_f16x2_launch(a, full, c->n_cus, st);
