@@ -25,13 +25,14 @@ with N.Renderer(dev_index) as r:
     r.load_scene(os.path.join(ROOT, "lego_rust"))
     cam = N.camera_from_samples(os.path.join(ROOT, "lego_rust", "tf_reference_samples.json"), size, size, 64)
     ok = True
-    for dtype in ("f32", "bf16x3"):
+    # plain renders: contiguous bands; skip_dead / certify_zero: rows dealt out round-robin (distributed.partition_for), packed bands + one index_copy
+    for dtype, mode in (("f32", {}), ("bf16x3", {}), ("f32", {"skip_dead": True}), ("f32", {"certify_zero": True}), ("f16x2", {"certify_zero": True})):
         for kw in ({}, {"crop": (10, 7, size - 33, size - 21)}):       # ragged bands: (size - 21) rows over `world` ranks
-            full = N.render_image(r.coarse, r.fine, cam, 128, seed=4, dtype=dtype, **kw)
-            got = N.render_image_distributed(r.coarse, r.fine, cam, 128, seed=4, dtype=dtype, **kw)
+            full = N.render_image(r.coarse, r.fine, cam, 128, seed=4, dtype=dtype, **kw)   # the PLAIN frame: the skipping modes must reproduce it too
+            got = N.render_image_distributed(r.coarse, r.fine, cam, 128, seed=4, dtype=dtype, **mode, **kw)
             same = bool((got == full).all()) and got.shape == full.shape
             ok = ok and same
-            print(f"rank {rank}/{world} {dtype} {kw or 'full'}: {'identical' if same else 'MISMATCH'}", flush=True)
+            print(f"rank {rank}/{world} {dtype} {mode or 'plain'} {kw or 'full'}: {'identical' if same else 'MISMATCH'}", flush=True)
 flag = torch.tensor([1 if ok else 0])
 if backend == "nccl":
     flag = flag.cuda()
