@@ -12,7 +12,7 @@ for b in (f"bench_{tag}.json", f"bench_gpu_{tag}.json"):
     if os.path.exists(os.path.join(ROOT, "gpurun_out", b)):
         shutil.copy(os.path.join(ROOT, "gpurun_out", b), os.path.join(dst, b))
 agg = collections.defaultdict(lambda: collections.defaultdict(float)); calls = collections.Counter(); dur = collections.defaultdict(float)
-for sub in ("pmc_sq", "pmc_fetch", "pmc_write"):
+for sub in ("pmc_sq", "pmc_fetch", "pmc_write", "pmc_lds"):
     f = os.path.join(src, sub, "bench_counter_collection.csv")
     if not os.path.exists(f):
         continue
@@ -44,6 +44,8 @@ for k, v in agg.items():
                  f"{100 * v['SQ_WAIT_ANY'] / wave:.1f} % waitcnt/barrier (SQ_WAIT_ANY), {100 * v['SQ_WAIT_INST_ANY'] / wave:.1f} % issue stall "
                  f"(SQ_WAIT_INST_ANY, i.e. waiting for the matrix pipe), {100 * v['SQ_ACTIVE_INST_ANY'] / wave:.1f} % issuing; "
                  f"HBM traffic per dispatch: FETCH_SIZE x2 (gfx950 correction) = {2 * v.get('FETCH_SIZE', 0) / 1024 / nd:.1f} MB, WRITE_SIZE = {v.get('WRITE_SIZE', 0) / 1024 / nd:.1f} MB "
-                 f"(algorithmic: weights 2.3 MB + inputs/outputs; the kernel is MFMA-bound, HBM is idle)")
+                 f"(algorithmic: weights 2.3 MB + inputs/outputs; the kernel is MFMA-bound, HBM is idle)" +
+                 (f"; LDS: {100 * v['SQ_LDS_BANK_CONFLICT'] / v['SQ_LDS_IDX_ACTIVE']:.2f} % of the LDS-array cycles are bank-conflict cycles (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE), "
+                  f"unaligned-access stalls {v.get('SQ_LDS_UNALIGNED_STALL', 0):.3g}, address conflicts {v.get('SQ_LDS_ADDR_CONFLICT', 0):.3g}" if v.get("SQ_LDS_IDX_ACTIVE") else ""))
 open(os.path.join(dst, f"{tag}_summary.md"), "w").write("\n".join(lines) + "\n")
 print("\n".join(lines[-4:]))
