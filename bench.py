@@ -487,7 +487,7 @@ def main():
                       "note": "opt-in certify_zero (DESIGN 4.9): a 16-bit pass (f16 operands where the network fits the f16 range -- lego does --, else bf16) over all samples certifies those whose density pre-activation is below minus the "
                               "network's margin as zeros of the f32 network too and predicts each ray's T < 1e-4 cut; the f32 MFMA kernel evaluates only the "
                               "other samples in front of the predicted cut (a device-side list), the exact transmittance confirms the cut; certified samples "
-                              "and samples behind the cut have weight 0, so the frame is the headline frame bit for bit; one certified sample in 64 is "
+                              "and samples behind the cut have weight 0, so the frame is the headline frame bit for bit; 1 in 16 of the samples certified by less than twice the margin and 1 in 128 of the others are "
                               "evaluated all the same (the audit: a wrong or nearly wrong certificate widens the margin and the frame is rendered again); "
                               "fuzzed: tools/fuzz_certify.py"}
         r.kernel_time_query(reset=True)

@@ -110,7 +110,7 @@ typedef struct {
                            * EXACT transmittance then confirms each cut, and where it does not (rare) the rest of that ray is evaluated in a
                            * second launch -- so (C) is exact by construction.  A certified sample has sigma = 0, weight 0 (src/lib.rs:271-272):
                            * the image is BIT-IDENTICAL to certify_zero = 0 as long as no certificate (Z) is wrong.
-                           * (Z) rests on measurements, not on a proof, so it is AUDITED in every frame: one certified sample in 64 (1 in 16 of those certified by
+                           * (Z) rests on measurements, not on a proof, so it is AUDITED in every frame: a deterministic share of the certified samples (1 in 16 of those certified by
                            * less than twice the margin, 1 in 128 of the others) is evaluated
                            * exactly all the same; a positive density there (nerf_stats.n_certify_violations), or an audited sample on which the 16-bit
                            * pass was off by more than half the margin (nerf_stats.certify_max_error, certify_headroom), widens that network's margin for the life of
@@ -156,7 +156,7 @@ typedef struct {
                                     * counters (nerf_render_image, nerf_render_image_multi, nerf_render_image_device with stats != NULL) fail
                                     * with NERF_ERR_STATE -- the stats are filled all the same. */
     /* certify_zero (ABI 5): the audit of the frame that was returned, see nerf_render_opts.certify_zero */
-    uint64_t n_certify_audited;    /* certified samples that the exact kernel evaluated all the same (about 1 in 64: denser near the margin) */
+    uint64_t n_certify_audited;    /* certified samples that the exact kernel evaluated all the same (1 in 16 of those within twice the margin, 1 in 128 of the others) */
     uint64_t n_certify_violations; /* audited samples whose exact density was positive, summed over ALL renders of this frame (the last one had none) */
     uint32_t n_certify_retries;    /* times the frame was rendered again (margins widened after a failed audit, or the sample list enlarged) */
     uint32_t n_certify_fallback_rays; /* rays whose predicted cut the exact transmittance did not confirm (their remaining samples went through a second launch) */

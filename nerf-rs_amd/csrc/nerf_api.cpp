@@ -825,7 +825,7 @@ int render_once(nerf_ctx *c, const nerf_camera *cam, const nerf_render_opts *o, 
 
 } // namespace
 
-// certify_zero frames are AUDITED (k_cert_audit: one certified sample in 64 is evaluated exactly all the same).  A frame stands only if no
+// certify_zero frames are AUDITED (k_cert_audit: 1 in 16 of the samples certified by less than twice the margin and 1 in 128 of the others are evaluated exactly all the same).  A frame stands only if no
 // audited certificate was wrong and the closest audited sample kept at least half the margin between itself and a positive density;
 // otherwise the network's margin is widened -- for good: c->cert_margin is per context and network, reset when a network is loaded --
 // and the frame is rendered again.  The same loop grows the sample list when a pass wanted more entries than it had.  Margins are

@@ -3,8 +3,8 @@ far below 0 and (C) predicts each ray's T < 1e-4 cut (src/lib.rs:276-279); the e
 fine pass of a split arithmetic that arithmetic's kernel) evaluates only the other samples in front of the predicted cut, the exact
 transmittance confirms the cut.  A certified sample has sigma = 0 in the exact network too, hence weight 0 (src/lib.rs:271-272), a
 sample behind the cut has weight 0 whatever its density: the frame must be the plain frame BIT FOR BIT -- which the whole-frame
-fixture tests hold to Gate 1 against the oracle (tests/test_gpu_frame_fixture.py).  (Z) is audited in every frame (1 certified sample
-in 64 is evaluated exactly all the same): a network on which the margins are too tight must widen them, certify nothing, or fail --
+fixture tests hold to Gate 1 against the oracle (tests/test_gpu_frame_fixture.py).  (Z) is audited in every frame (1 certified sample in 16 near the margin,
+1 in 128 below it, is evaluated exactly all the same): a network on which the margins are too tight must widen them, certify nothing, or fail --
 never return a silently different frame."""
 import os
 import sys
