@@ -41,6 +41,16 @@ def test_c3_whole_frame_is_the_f32_frame(renderer, native, samples):
     assert st.n_certify_fallback_rays < 0.01 * st.n_rays
 
 
+def test_c5_geometry_three_passes(renderer, native, samples):
+    """Config C5's geometry (800 x 800 output, 2 x 2 SSAA = 2.56 M rays: three passes of whole ray rows) in the f16x2 arithmetic: the certified frame is the
+    plain f16x2 frame bit for bit (bench.py reports its rate beside the bf16 rows: extra_c5_bf16_ssaa2.same_geometry_at_f32_accuracy_...)."""
+    cam = native.camera_from_samples(samples, 800, 800, 64)
+    ref = native.render_image(renderer.coarse, renderer.fine, cam, 128, seed=3, dtype="f16x2", ssaa=2)
+    img, st = native.render_image(renderer.coarse, renderer.fine, cam, 128, seed=3, dtype="f16x2", ssaa=2, certify_zero=True, return_stats=True)
+    assert np.array_equal(img, ref)
+    assert st.n_passes >= 2 and st.n_certify_violations == 0 and st.n_rays == 4 * 800 * 800
+
+
 @pytest.mark.parametrize("nc,nf,W,crop,coarse_only,ssaa,pose_deg", [
     (64, 128, 800, (300, 300, 200, 64), False, 1, None), (40, 50, 800, (380, 360, 40, 24), False, 1, None), (64, 0, 800, (200, 200, 300, 100), True, 1, None),
     (33, 31, 800, (0, 0, 800, 8), False, 1, None), (64, 128, 800, (395, 400, 1, 1), False, 1, None), (64, 128, 128, None, False, 2, None),
