@@ -155,13 +155,11 @@ __global__ __launch_bounds__(256) void k_resample(ResampleArgs a) {
     }
     wave_sync();
     float sum = 0.0f;
-#pragma unroll 8
-    for (int i = 0; i < m; ++i) sum += alpha[i];                 // iter().sum(), sequential (unrolled: the LDS reads batch, the adds keep their order)
+    for (int i = 0; i < m; ++i) sum += alpha[i];                 // iter().sum(), sequential
     wave_sync();
     for (int i = lane; i < m; i += 64) alpha[i] = alpha[i] / sum;
     wave_sync();
     float cumulative = 0.0f;
-#pragma unroll 8
     for (int i = 0; i < m; ++i) { cumulative += alpha[i]; if (lane == 0) cdf[i + 1] = cumulative; }
     if (lane == 0) { cdf[0] = 0.0f; cdf[m] = 1.0f; }             // :320, :326-328
     wave_sync();
